@@ -1,0 +1,352 @@
+/*
+ * rt_hip.h -- C ABI of librt_hip.so, the MI355X (gfx950) implementation of
+ * raytrace's per-pixel path-tracing loop.
+ *
+ * The reference has no FFI of its own; the seam this library plugs into is the
+ * Go function renderScene(ctx, *Scene, Camera) (phys/render.go:285-349), called
+ * only from phys.Render (phys/render.go:351-364).  Every entry point below cites
+ * the reference code whose behaviour it replaces.
+ *
+ * Conventions
+ *   - plain C types only; all geometry is float64 in the caller's world units
+ *     (the reference uses nanometres, phys/distance.go:7-19);
+ *   - every function returns RT_OK (0) or a negative RT_ERR_* code and leaves a
+ *     human readable message retrievable with rt_last_error() (thread local);
+ *   - the caller owns every input array; the library deep-copies what it needs
+ *     during the call, so no pointer has to outlive the call that received it
+ *     (this is what cgo's pointer-passing rules require).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)         /* bad argument / inconsistent scene description */
+#define RT_ERR_UNSUPPORTED (-2)     /* valid in the reference, not handled by this library */
+#define RT_ERR_DEVICE (-3)          /* a HIP call failed (message carries hipGetErrorString) */
+#define RT_ERR_CANCELLED (-4)       /* rt_cancel() was called; mirrors ctx.Err() (render.go:340-343) */
+#define RT_ERR_NOMEM (-5)
+#define RT_ERR_NOT_INITIALIZED (-6) /* rt_init() has not been called */
+
+/* ---- shapes (phys/shape_*.go) ------------------------------------------------ */
+
+enum rt_shape_kind {
+    RT_SHAPE_SPHERE = 0,      /* phys.Sphere            shape_sphere.go:245-256  */
+    RT_SHAPE_QUAD = 1,        /* phys.Quad              shape_quad.go:15-20      */
+    RT_SHAPE_CYLINDER = 2,    /* phys.Cylinder          shape_cylinder.go:13-18  */
+    RT_SHAPE_TRIANGLE = 3,    /* phys.Triangle / TriangleUV / a lone Face         */
+    RT_SHAPE_MESH = 4,        /* phys.Mesh (BVH over Faces) shape_mesh.go:164-167 */
+    RT_SHAPE_TRANSFORMED = 5  /* phys.TransformedShape  shape_transformed_shape.go:12-15 */
+};
+
+enum rt_uvmap_kind { /* phys.UVMapKind, shape_sphere.go:212-226 */
+    RT_UVMAP_EQUIRECT = 0,
+    RT_UVMAP_EQUIRECT_SOUTH_UP = 1,
+    RT_UVMAP_BOX = 2
+};
+
+enum rt_triangle_kind {
+    RT_TRI_TRIANGLE = 0,    /* phys.Triangle:   eps 1e-6, uv = (u,v), normal = unit(e1 x e2)  shape_triangle.go:105-139 */
+    RT_TRI_TRIANGLE_UV = 1, /* phys.TriangleUV: eps 1e-6, uv = UV0.Lerp(UV1,u)+UV2*v, stored normal  shape_triangle_uv.go:117-150 */
+    RT_TRI_FACE = 2         /* phys.Face:       eps 1e-8, barycentric uv, normal = unit(e1 x e2)  shape_mesh.go:95-142 */
+};
+
+typedef struct rt_sphere {
+    double center[3];
+    double radius;
+    int32_t uvmap; /* rt_uvmap_kind */
+    int32_t reserved;
+} rt_sphere;
+
+typedef struct rt_quad {
+    double center[3];
+    double normal[3];
+    double width;
+    double height;
+} rt_quad;
+
+typedef struct rt_cylinder {
+    double origin[3];
+    double direction[3];
+    double radius;
+    double height;
+} rt_cylinder;
+
+typedef struct rt_triangle {
+    double p[3][3];   /* P0, P1, P2 */
+    double uv[3][2];  /* UV0..UV2 (TriangleUV, Face); ignored for Triangle */
+    double normal[3]; /* stored Normal (TriangleUV only) */
+    int32_t kind;     /* rt_triangle_kind */
+    int32_t reserved;
+} rt_triangle;
+
+/* One mesh face.  Identical to the in-memory layout of the Go value
+ * phys.Face{Vertex [3]Vertex{Position r3.Point; UV r2.Point}} (shape_mesh.go:12-21):
+ * 3 x (x, y, z, u, v) float64 = 120 bytes, so a Go []Face can be passed as is. */
+typedef struct rt_face {
+    double v[3][5];
+} rt_face;
+
+/* phys.Mesh: a run of faces in rt_scene_desc.faces.  The library builds the BVH
+ * itself with the reference's binned-SAH rules (NewBVH, shape_bvh.go:81-272), so
+ * a host may skip NewMesh's own build. */
+typedef struct rt_mesh {
+    uint64_t first_face;
+    uint64_t n_faces;
+} rt_mesh;
+
+/* phys.TransformedShape{Shape, Transform{Translation, Rotation, Scale}}
+ * (shape_transformed_shape.go:12-15, transform.go:53-57).  The child may be any
+ * shape kind, another RT_SHAPE_TRANSFORMED included. */
+typedef struct rt_transformed {
+    int32_t child_kind;  /* rt_shape_kind */
+    int32_t child_index; /* index into the array of that kind */
+    double translation[3];
+    double rotation[9]; /* row major r3.Mat3x3.M */
+    double scale[3];
+} rt_transformed;
+
+/* ---- textures, materials, lights ---------------------------------------------- */
+
+enum rt_texture_kind {
+    RT_TEX_UNIFORM = 0,      /* phys.TextureUniform       texture_uniform.go:13-20 */
+    RT_TEX_CHECKERBOARD = 1, /* phys.TextureCheckerboard  texture_checkerboard.go:21-69 */
+    RT_TEX_IMAGE = 2         /* phys.TextureImage         texture_image.go:18-136 */
+};
+enum rt_interp_kind { RT_INTERP_NEAREST = 0, RT_INTERP_BILINEAR = 1 }; /* TextureImage.Interp: "bilinear" or anything else */
+enum rt_wrap_kind { RT_WRAP_REPEAT = 0, RT_WRAP_CLAMP = 1 };           /* TextureImage.WrapMode: "clamp" or anything else */
+
+enum rt_image_format {
+    RT_IMG_NRGBA8 = 0, /* 4 x uint8 non-premultiplied (Go image.NRGBA, what png.Decode yields for RGBA PNGs) */
+    RT_IMG_RGBA16 = 1  /* 4 x uint16 alpha-premultiplied, i.e. the values color.Color.RGBA() returns */
+};
+
+typedef struct rt_image {
+    int32_t width;
+    int32_t height;
+    int32_t format;     /* rt_image_format */
+    int32_t reserved;
+    const void* pixels; /* row major, row 0 = top, tightly packed */
+} rt_image;
+
+typedef struct rt_texture {
+    int32_t kind;     /* rt_texture_kind */
+    int32_t odd;      /* checkerboard: texture index of Odd  */
+    int32_t even;     /* checkerboard: texture index of Even */
+    int32_t image;    /* image: index into images */
+    int32_t interp;   /* rt_interp_kind */
+    int32_t wrap;     /* rt_wrap_kind */
+    double color[3];  /* uniform */
+    double frequency; /* checkerboard */
+} rt_texture;
+
+enum rt_material_kind {
+    RT_MAT_LAMBERTIAN = 0,  /* material_lambertian.go  */
+    RT_MAT_METAL = 1,       /* material_metal.go       */
+    RT_MAT_DIELECTRIC = 2,  /* material_dielectric.go  */
+    RT_MAT_EMITTER = 3,     /* material_emitter.go     */
+    RT_MAT_DEBUG_UV = 4,    /* material_debug_uv.go    */
+    RT_MAT_DEBUG_NORMAL = 5 /* material_debug_normal.go */
+};
+
+typedef struct rt_material {
+    int32_t kind;    /* rt_material_kind */
+    int32_t texture; /* Lambertian / Emitter: texture index */
+    double albedo[3];     /* Metal.Albedo */
+    double fuzz;          /* Metal.Fuzz */
+    double ior_interior;  /* Dielectric.RefractiveIndexInterior */
+    double ior_exterior;  /* Dielectric.RefractiveIndexExterior */
+    double roughness;     /* Dielectric.Roughness */
+} rt_material;
+
+typedef struct rt_light { /* phys.PointLight, light.go:16-19 */
+    double position[3];
+    double intensity[3];
+} rt_light;
+
+typedef struct rt_node { /* phys.Node{Shape, Material}, node.go:21-26 */
+    int32_t shape_kind;  /* rt_shape_kind */
+    int32_t shape_index; /* index into the array of that kind */
+    int32_t material;    /* index into materials */
+    int32_t reserved;
+} rt_node;
+
+/* A whole phys.Scene minus cameras and RenderOptions (scene.go:9-14), flattened. */
+typedef struct rt_scene_desc {
+    const rt_node* nodes;             uint64_t n_nodes;
+    const rt_sphere* spheres;         uint64_t n_spheres;
+    const rt_quad* quads;             uint64_t n_quads;
+    const rt_cylinder* cylinders;     uint64_t n_cylinders;
+    const rt_triangle* triangles;     uint64_t n_triangles;
+    const rt_mesh* meshes;            uint64_t n_meshes;
+    const rt_face* faces;             uint64_t n_faces;
+    const rt_transformed* transformed; uint64_t n_transformed;
+    const rt_material* materials;     uint64_t n_materials;
+    const rt_texture* textures;       uint64_t n_textures;
+    const rt_image* images;           uint64_t n_images;
+    const rt_light* lights;           uint64_t n_lights;
+} rt_scene_desc;
+
+/* ---- cameras (phys/camera_*.go) ------------------------------------------------ */
+
+enum rt_camera_kind {
+    RT_CAM_PINHOLE = 0,      /* camera_pinhole.go:12-34      */
+    RT_CAM_FOCUSABLE = 1,    /* camera_focusable.go:14-63    */
+    RT_CAM_ORTHOGRAPHIC = 2, /* camera_orthographic.go:14-46 */
+    RT_CAM_CALIBRATED = 3    /* camera_calibrated.go:32-79, 110-136, 172-199 */
+};
+
+/* phys.AnimatedCamera (camera_animated.go:70-74) is a Go closure; the host
+ * resolves it to one of the four concrete kinds before calling. */
+typedef struct rt_camera_desc {
+    int32_t kind; /* rt_camera_kind */
+    int32_t reserved;
+    /* Focusable / Orthographic / Calibrated extrinsics */
+    double look_from[3];
+    double look_at[3];
+    double vup[3];
+    double fov_height;
+    double fov_width;
+    double aperture;         /* Focusable */
+    double working_distance; /* Focusable */
+    /* Pinhole */
+    double lower_left_corner[3];
+    double origin[3];
+    double horizontal[3];
+    double vertical[3];
+    /* Calibrated intrinsics (CameraIntrinsics) */
+    int32_t width;
+    int32_t height;
+    double fx, fy, cx, cy;
+    double k1, k2, p1, p2, k3, k4, k5, k6;
+} rt_camera_desc;
+
+/* ---- render ------------------------------------------------------------------------ */
+
+enum rt_mode {
+    /* float64 everywhere, BVH visited in the reference's order (left child first,
+     * shrinking tmax, shape_bvh.go:44-78) with Go's NaN-propagating Max/Min:
+     * hits are bit-identical to the reference algorithm's. */
+    RT_MODE_REFERENCE = 0,
+    /* float32 conservative box culling, nearest-child-first order, any-hit shadow
+     * rays; primitives are still intersected in float64 so t/uv/normal of the hit
+     * primitive are the reference's values. */
+    RT_MODE_FAST = 1
+};
+
+typedef struct rt_render_opts { /* phys.RenderOptions, render.go:73-79 */
+    int64_t seed;
+    int32_t rays_per_pixel;
+    int32_t max_ray_depth;
+    int32_t dx;
+    int32_t dy;
+    int32_t mode; /* rt_mode */
+    /* Row-band sharding: the image is cut into bands of 16 rows (the reference's
+     * tile height, render.go:298); this call renders band b iff
+     * b % band_world == band_rank.  1 process: band_rank 0, band_world 1. */
+    int32_t band_rank;
+    int32_t band_world;
+    int32_t reserved;
+    void* stream; /* hipStream_t to launch on; NULL = the null stream */
+} rt_render_opts;
+
+typedef struct rt_stats { /* phys.RenderStats, render.go:38-45 */
+    uint64_t total_rays;          /* every tracePath call (render.go:143) */
+    uint64_t rays_exceeded_depth; /* render.go:151-153 */
+    uint64_t rays_left_scene;     /* render.go:170-172 */
+    uint64_t shadow_rays;         /* occlusion rays; the reference does not count these */
+    double render_seconds;        /* wall time of the call, scene already resident */
+    double traverse_seconds;      /* sum of HIP-event time of the closest-hit traversal launches */
+    uint64_t traverse_launches;
+    uint64_t traverse_rays;       /* rays those launches processed */
+} rt_stats;
+
+typedef struct rt_hit {
+    int32_t node;    /* index of the scene node hit, -1 = miss */
+    int32_t prim;    /* face index inside the mesh (order of rt_scene_desc.faces), else 0 */
+    double t;
+    double at[3];
+    double normal[3];
+    double uv[2];
+    uint32_t boxes_tested; /* AABB.hit calls made for this ray (reference order only) */
+    uint32_t prims_tested; /* Face.Collide calls made for this ray (reference order only) */
+} rt_hit;
+
+typedef struct rt_scene rt_scene;
+
+/* Select the GPUs this process uses (device ordinals) and create per-device
+ * state.  gpu_ids == NULL or n == 0 selects device 0.  Replaces nothing in the
+ * reference (it is CPU only); called once from the Go package's init. */
+int rt_init(const int* gpu_ids, int n);
+void rt_shutdown(void);
+
+/* Thread-local message of the last failing call on this thread.  Go wraps it as
+ * fmt.Errorf("failed to render scene: %v", ...) like render.go:361. */
+const char* rt_last_error(void);
+
+/* Deep-copies the scene to the device: flattens shapes, builds every mesh BVH
+ * (NewBVH, shape_bvh.go:81-272), uploads textures.  Performs the checks of
+ * Scene.Validate that concern the arrays (scene.go:29-79). */
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Replacement for the body of renderScene (render.go:285-349): renders
+ * opts->dx x opts->dy pixels with opts->rays_per_pixel samples each and writes
+ * 8-bit RGBA (A = 255, row 0 = top) into rgba_out, `stride` bytes per row, the
+ * layout of image.RGBA.Pix.  Blocking.  One render in flight per scene handle. */
+int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts,
+              uint8_t* rgba_out, size_t stride, rt_stats* stats);
+
+/* The same render, stopping before quantisation: adds this call's radiance sums
+ * into film_dev, a DEVICE buffer of dx*dy*3 float64 (row 0 = top, RGB), which
+ * the caller zeroes first.  With band sharding each process fills only its
+ * bands, so summing the films of all processes (one RCCL reduce) gives the whole
+ * image.  No counterpart in the reference: this is the multi-GPU seam. */
+int rt_render_film(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts,
+                   double* film_dev, rt_stats* stats);
+
+/* Quantise a summed film exactly as renderPixel does (render.go:218-224):
+ * c = sum / rays_per_pixel; byte = uint8(min(255, 255.99 * c)).  rgba_out is a
+ * host buffer. */
+int rt_film_resolve(const double* film_dev, int32_t dx, int32_t dy, int32_t rays_per_pixel,
+                    uint8_t* rgba_out, size_t stride, void* stream);
+
+/* Request cancellation of the render running on `scene` (from another thread).
+ * rt_render then returns RT_ERR_CANCELLED; mirrors ctx.Done() (render.go:229-233, 340-343). */
+void rt_cancel(rt_scene* scene);
+
+/* Closest hit of n rays against the scene, the loop of tracePath over
+ * scene.Node (render.go:155-169): nodes in order, Shape.Collide(r, tmin, minDist),
+ * keep when c.t < minDist; minDist starts at tmax.  o and d are n x 3 float64
+ * host arrays; hits is a host array of n records. */
+int rt_intersect_batch(rt_scene* scene, const double* o, const double* d, uint64_t n,
+                       double tmin, double tmax, int mode, rt_hit* hits);
+
+/* Primary rays for an explicit list of samples: (s, t) in [0,1]^2 per ray as
+ * Camera.Cast receives them (camera.go:12-15), plus the pixel / sample index
+ * that key the random stream (FocusableCamera draws a lens point).  Writes
+ * n x 3 origins and directions to host arrays.  Test entry point. */
+int rt_cast_batch(const rt_camera_desc* camera, const double* st, const uint32_t* pixel_sample,
+                  uint64_t n, int64_t seed, double* o_out, double* d_out);
+
+/* Per-mesh BVH statistics of a created scene (nodes, leaves, depth). */
+typedef struct rt_bvh_info {
+    uint64_t n_faces;
+    uint64_t n_nodes;  /* BVH structs in the reference's tree */
+    uint64_t n_leaves;
+    uint32_t max_depth;
+    uint32_t max_leaf_size;
+    double build_seconds;
+} rt_bvh_info;
+int rt_scene_bvh_info(const rt_scene* scene, uint64_t mesh_index, rt_bvh_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

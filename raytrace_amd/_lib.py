@@ -1,0 +1,72 @@
+"""Loader for librt_hip.so (the C ABI of include/rt_hip.h).  There is no fallback:
+if the library is missing or fails to load, every render call raises."""
+import ctypes as C
+import os
+
+from . import abi
+
+_LIB = None
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_hip.so")
+
+SYMBOLS = [
+    "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
+    "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info",
+]
+
+
+def lib_path() -> str:
+    return _PATH
+
+
+def open_library() -> C.CDLL:
+    """dlopen the library and declare signatures; does not touch the GPU."""
+    if not os.path.exists(_PATH):
+        raise RuntimeError(f"{_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(_PATH)
+    P = C.POINTER
+    lib.rt_init.argtypes = [P(C.c_int), C.c_int]
+    lib.rt_init.restype = C.c_int
+    lib.rt_shutdown.argtypes = []
+    lib.rt_shutdown.restype = None
+    lib.rt_last_error.argtypes = []
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_scene_create.argtypes = [P(abi.SceneDesc), P(C.c_void_p)]
+    lib.rt_scene_create.restype = C.c_int
+    lib.rt_scene_destroy.argtypes = [C.c_void_p]
+    lib.rt_scene_destroy.restype = None
+    lib.rt_render.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), P(C.c_uint8), C.c_size_t, P(abi.Stats)]
+    lib.rt_render.restype = C.c_int
+    lib.rt_render_film.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), C.c_void_p, P(abi.Stats)]
+    lib.rt_render_film.restype = C.c_int
+    lib.rt_film_resolve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, P(C.c_uint8), C.c_size_t, C.c_void_p]
+    lib.rt_film_resolve.restype = C.c_int
+    lib.rt_cancel.argtypes = [C.c_void_p]
+    lib.rt_cancel.restype = None
+    lib.rt_intersect_batch.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double), C.c_uint64, C.c_double, C.c_double,
+                                       C.c_int, P(abi.Hit)]
+    lib.rt_intersect_batch.restype = C.c_int
+    lib.rt_cast_batch.argtypes = [P(abi.CameraDesc), P(C.c_double), P(C.c_uint32), C.c_uint64, C.c_int64, P(C.c_double),
+                                  P(C.c_double)]
+    lib.rt_cast_batch.restype = C.c_int
+    lib.rt_scene_bvh_info.argtypes = [C.c_void_p, C.c_uint64, P(abi.BvhInfo)]
+    lib.rt_scene_bvh_info.restype = C.c_int
+    return lib
+
+
+def check(code: int, lib) -> None:
+    if code != abi.RT_OK:
+        msg = lib.rt_last_error()
+        raise RuntimeError(f"librt_hip error {code}: {msg.decode() if msg else ''}")
+
+
+def load(device: int = None) -> C.CDLL:
+    """Open the library and initialise it on `device` (default: LOCAL_RANK or 0)."""
+    global _LIB
+    if _LIB is None:
+        lib = open_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        ids = (C.c_int * 1)(device)
+        check(lib.rt_init(ids, 1), lib)
+        _LIB = lib
+    return _LIB
