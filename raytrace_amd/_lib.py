@@ -22,6 +22,15 @@ def open_library() -> C.CDLL:
     """dlopen the library and declare signatures; does not touch the GPU."""
     if not os.path.exists(_PATH):
         raise RuntimeError(f"{_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    # PyTorch wheels bundle their own libamdhip64 (same SONAME).  A process that also uses torch
+    # (device tensors, torch.distributed / RCCL) must end up with ONE HIP runtime: importing
+    # torch first makes this library bind to the copy torch loaded.  RT_NO_TORCH=1 skips this
+    # and binds to the system ROCm runtime (what a Go / C host gets).
+    if os.environ.get("RT_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(_PATH)
     P = C.POINTER
     lib.rt_init.argtypes = [P(C.c_int), C.c_int]

@@ -1,0 +1,140 @@
+// Plain structs shared by the host code that uploads a scene and the kernels that read it.
+#pragma once
+
+#include <cstdint>
+
+#include "../../include/rt_hip.h"
+#include "bvh_build.h"
+
+namespace rt {
+
+struct DNode {
+    int32_t kind, index, material, pad;
+};
+
+struct DSphere {
+    double c[3];
+    double r;
+    int32_t uvmap, pad;
+};
+
+// Quad with the per-call set-up of Quad.Collide (shape_quad.go:40-64, 90-97) done once
+// on the host with the same float64 operations in the same order.
+struct DQuad {
+    double nrm[3];
+    double p0[3], p1[3], p2[3], p3[3];
+    double lu[3], lv[3];  // localU = p2 - p1, localV = p0 - p1
+    double lulu, lvlv;    // localU.localU, localV.localV
+};
+
+struct DCylinder {
+    double o[3];
+    double d[3];    // Direction.Unit() (shape_cylinder.go:41)
+    double top[3];  // Origin + d * Height (shape_cylinder.go:100)
+    double r, h;
+};
+
+struct DTri {
+    double p0[3], p1[3], p2[3];
+    double uv[6];
+    double n[3];  // Normal.Unit() for TriangleUV (shape_triangle_uv.go:147)
+    int32_t kind, pad;
+};
+
+struct DXform {  // transform.go:53-102
+    double tr[3];
+    double rot[9];
+    double sc[3];
+};
+
+struct DTransformed {
+    int32_t child_kind, child_index;
+    DXform fwd, inv;  // inv = Transform.Inverse() (transform.go:86-102)
+};
+
+struct DMesh {
+    int64_t ref_off;   // first RefNode of this mesh
+    int64_t fast_off;  // first FastNode
+    int64_t prim_off;  // first prim (leaf order) in prim_pos / prim_face
+    int64_t face_off;  // first face (caller order) in face_uv
+    double center[3];
+    double root_box[6];
+    float pad;
+    int32_t n_faces;
+};
+
+struct DImage {
+    const uint8_t* px;
+    int32_t w, h, format, pad;
+};
+
+struct DScene {
+    const DNode* nodes;
+    const DSphere* spheres;
+    const DQuad* quads;
+    const DCylinder* cylinders;
+    const DTri* tris;
+    const DTransformed* xforms;
+    const DMesh* meshes;
+    const RefNode* ref_nodes;
+    const FastNode* fast_nodes;
+    const double* prim_pos;    // 9 per prim, leaf order
+    const int32_t* prim_face;  // leaf order -> face index within its mesh
+    const double* face_uv;     // 6 per face, caller order
+    const rt_material* materials;
+    const rt_texture* textures;
+    const DImage* images;
+    const rt_light* lights;
+    int32_t n_nodes, n_lights;
+};
+
+struct DCamera {
+    int32_t kind, pad;
+    double from[3];
+    double u[3], v[3], w[3];  // basis (camera_orthographic.go:26-28 and friends)
+    double dir[3];            // orthographic: unit(LookAt - LookFrom)
+    double fov_w, fov_h;
+    double horizontal[3], vertical[3], llc[3];  // focusable / pinhole image plane
+    double lens_radius;
+    double origin[3];  // pinhole
+    rt_camera_desc intr;  // calibrated intrinsics are read from here
+};
+
+// One path segment waiting to be traced (render.go:22-30).
+struct RayRec {
+    double o[3];
+    double d[3];
+    double rad[3];     // ray.radiance
+    uint32_t pixel;    // film index: image row * dx + x (row 0 = top)
+    uint32_t sample;
+    uint32_t path;     // position in the path tree (root 1, children 2p, 2p+1)
+    uint32_t depth_n;  // depth << 24 | random draws made on this ray's stream
+};
+
+struct HitRec {  // shape.go:11-16 plus which node / face
+    int32_t node, prim;
+    double t;
+    double at[3];
+    double normal[3];
+    double uv[2];
+};
+
+// A lit surface point waiting for its light loop (material_*.go ComputeDirectLighting).
+struct SurfRec {
+    double p[3];
+    double n[3];       // normal used for the offset and the cosine (flipped inside a dielectric)
+    double wo[3];      // unit direction back along the incoming ray
+    double albedo[3];  // Lambertian texture value / Metal albedo
+    uint32_t pixel;
+    int32_t node;
+    int32_t material;
+    int32_t inside;    // dielectric: the hit was from inside
+};
+
+struct Counters {
+    unsigned long long total, exceeded, left, shadow;
+    unsigned int next_count, surf_count;
+    unsigned int pad[2];
+};
+
+}  // namespace rt
