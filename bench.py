@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on the einstein-scan configuration.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): the scan stand-in mesh
+(icosphere level 8, 1,310,720 faces; the real einstein.obj is not available), Emitter +
+4096^2 bilinear image texture, orthographic camera of example/scan, 3840x2160, 1024 rays per
+pixel, fast mode.  One "step" renders `--spp-step` consecutive sample indices of every pixel of
+the frame (default 64, so 16 steps are the whole 1024-spp frame); the rows of the frame are cut
+into 16-row bands dealt round-robin to the ranks, every rank keeps the whole scene in its own
+HBM, and the per-rank films are summed onto rank 0 with one RCCL reduce after the last step.
+
+Prints ONE JSON line on rank 0.  `value` is TotalRays (the reference's RenderStats counter,
+render.go:143) of all ranks divided by the slowest rank's wall time for the K timed steps.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, GB/s
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=4)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--spp-step", type=int, default=64, help="sample indices rendered per step")
+    p.add_argument("--level", type=int, default=8, help="icosphere level of the stand-in mesh (8 = 1.31 M faces)")
+    p.add_argument("--dx", type=int, default=3840)
+    p.add_argument("--dy", type=int, default=2160)
+    p.add_argument("--spp", type=int, default=1024, help="RaysPerPixel of the configuration")
+    p.add_argument("--tex", type=int, default=4096)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
+    p.add_argument("--check", action="store_true", help="compare a crop of the GPU image with the oracle")
+    return p.parse_args()
+
+
+def cpu_baseline(scene, opts, target_seconds):
+    """Times the CPU oracle (the restatement of the reference algorithm) on a bounded sample of
+    the same workload: every 8th tile row and column of the frame (1/64 of the tiles), with as
+    many sample indices as fit the time budget.  Also returns the reference-order visit counts
+    (boxes and faces tested per mesh ray) that price the algorithmic bytes of a ray."""
+    from oracle import binding as ob
+    from raytrace_amd import phys
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    with ob.OracleScene(scene) as orc:
+        probe = phys.RenderOptions(opts.Seed, opts.RaysPerPixel, opts.MaxRayDepth, opts.Dx, opts.Dy)
+        ro = phys.render_opts(probe, sample_begin=0, sample_count=1)
+        img, st, ex, _ = _oracle_render(orc, scene, probe, ro, cores, 8)
+        rate = st.total_rays / max(st.render_seconds, 1e-9)
+        n_samples = int(max(1, min(opts.RaysPerPixel, target_seconds * rate / max(st.total_rays, 1))))
+        ro = phys.render_opts(probe, sample_begin=0, sample_count=n_samples)
+        img, st, ex, _ = _oracle_render(orc, scene, probe, ro, cores, 8)
+    return {
+        "value": st.total_rays / st.render_seconds / 1e6,
+        "unit": "Mrays/s",
+        "cores": int(ex.threads_used),
+        "kind": "port",
+        "sample": f"C++ float64 restatement of the reference algorithm (-O2, no FMA), 16x16 tile queue, every 8th tile row and "
+                  f"column of the {opts.Dx}x{opts.Dy} frame x {n_samples} sample indices = {st.total_rays} rays in "
+                  f"{st.render_seconds:.2f} s",
+        "boxes_per_ray": ex.boxes_tested / max(ex.mesh_rays, 1),
+        "faces_per_ray": ex.prims_tested / max(ex.mesh_rays, 1),
+        "miss_fraction": st.rays_left_scene / max(st.total_rays, 1),
+    }
+
+
+def _oracle_render(orc, scene, options, ro, cores, tile_step):
+    import numpy as np
+    from oracle import binding as ob
+    from raytrace_amd import abi, phys
+    img = np.zeros((options.Dy, options.Dx, 4), dtype=np.uint8)
+    st = abi.Stats()
+    ex = ob.RenderExtra(cores, tile_step, None)
+    cd = phys.camera_desc(scene.Camera[0])
+    rc = orc.lib.oracle_render(orc.handle, C.byref(cd), C.byref(ro), img.ctypes.data_as(C.POINTER(C.c_uint8)), options.Dx * 4,
+                               C.byref(st), C.byref(ex))
+    assert rc == 0
+    return img, st, ex, None
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from raytrace_amd import _lib, abi, phys, scenes
+
+    lib = _lib.load(local_rank)
+    scene = scenes.scan(level=a.level, dx=a.dx, dy=a.dy, spp=a.spp, depth=10, seed=0, tex_size=a.tex)
+    o = scene.RenderOptions
+    t0 = time.time()
+    dev = phys.DeviceScene(scene)
+    upload_s = time.time() - t0
+    info = dev.bvh_info(0)
+    cd = phys.camera_desc(scene.Camera[0])
+    film = torch.zeros((o.Dy, o.Dx, 3), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k):
+        s0 = (k * a.spp_step) % o.RaysPerPixel
+        cnt = min(a.spp_step, o.RaysPerPixel - s0)
+        ro = phys.render_opts(o, abi.MODE_FAST, rank, world, stream, s0, cnt)
+        st = abi.Stats()
+        _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(a.warmup):
+        step(k)
+    film.zero_()
+    fence()
+    t_begin = time.perf_counter()
+    rays = trav_s = 0.0
+    trav_launches = trav_rays = 0
+    for k in range(a.steps):
+        st = step(k)
+        rays += st.total_rays
+        trav_s += st.traverse_seconds
+        trav_launches += st.traverse_launches
+        trav_rays += st.traverse_rays
+    if world > 1:  # the per-GPU films hold disjoint row bands: one sum onto rank 0 combines them
+        dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+    fence()
+    elapsed = time.perf_counter() - t_begin
+    tot = torch.tensor([rays, elapsed, trav_s, float(trav_launches), float(trav_rays)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[1])
+    rays_all = float(tot[0])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    out_img = np.zeros((o.Dy, o.Dx, 4), dtype=np.uint8)
+    spp_done = min(a.steps * a.spp_step, o.RaysPerPixel)
+    _lib.check(lib.rt_film_resolve(C.c_void_p(film.data_ptr()), o.Dx, o.Dy, max(spp_done, 1),
+                                   out_img.ctypes.data_as(C.POINTER(C.c_uint8)), o.Dx * 4, None), lib)
+    value = rays_all / elapsed / 1e6
+    result = {
+        "metric": "Mrays/sec (whole node), einstein-scan mesh 4K",
+        "value": value,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / max(a.steps, 1),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"example/scan stand-in: displaced icosphere {info.n_faces} faces (einstein.obj is not in the reference tree), "
+                        f"Emitter + {a.tex}x{a.tex} bilinear image texture, orthographic camera, {o.Dx}x{o.Dy} @ {o.RaysPerPixel} spp, "
+                        f"MaxRayDepth {o.MaxRayDepth}; one step = {a.spp_step} sample indices of every pixel",
+            "mode": "fast (float32 conservative box culling, float64 face intersection)",
+            "parallelism": f"16-row bands round-robin over {world} GPU(s), scene replicated, one RCCL reduce of the film",
+            "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.max_depth), "bvh_build_s": info.build_seconds,
+            "scene_upload_s": upload_s,
+            "rays_per_step_all_gpus": rays_all / max(a.steps, 1),
+        },
+    }
+    base = None
+    if not a.no_cpu_baseline:
+        base = cpu_baseline(scene, o, a.cpu_seconds)
+        result["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
+    # roofline of the dominant kernel (k_extend, closest-hit traversal), rank 0's launches:
+    # algorithmic bytes of a ray = 32 (ray in) + 32 * boxes tested + 48 * faces tested + 16 (hit out),
+    # with the box / face counts of the REFERENCE-order traversal measured by the CPU oracle.
+    if base is not None and trav_launches > 0:
+        bytes_per_ray = 32.0 + 32.0 * base["boxes_per_ray"] + 48.0 * base["faces_per_ray"] + 16.0
+        # HIP-event time of rank 0's traversal launches during the timed steps
+        my_rays = float(trav_rays)
+        my_secs = float(trav_s)
+        achieved = bytes_per_ray * my_rays / max(my_secs, 1e-12) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("k_extend_hbm_bytes_per_launch")
+        result["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "k_extend<fast>", "bytes_per_ray": bytes_per_ray, "boxes_per_ray": base["boxes_per_ray"],
+            "faces_per_ray": base["faces_per_ray"], "rays_per_launch": my_rays / max(float(trav_launches), 1.0),
+            "avg_launch_ms": 1e3 * my_secs / max(float(trav_launches), 1.0), "miss_fraction": base["miss_fraction"],
+        }
+    if a.check:
+        from oracle import binding as ob
+        with ob.OracleScene(scene) as orc:
+            probe = phys.RenderOptions(o.Seed, o.RaysPerPixel, o.MaxRayDepth, o.Dx, o.Dy)
+            ro = phys.render_opts(probe, sample_begin=0, sample_count=spp_done)
+            ref, _, _, _ = _oracle_render(orc, scene, probe, ro, 16, 16)
+        mask = ref[..., 3] == 255
+        diff = np.abs(out_img[mask][:, :3].astype(int) - ref[mask][:, :3].astype(int))
+        result["check"] = {"pixels": int(mask.sum()), "max_abs_diff": int(diff.max()), "frac_diff_gt1": float((diff > 1).mean())}
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -252,6 +252,11 @@ typedef struct rt_render_opts { /* phys.RenderOptions, render.go:73-79 */
      * b % band_world == band_rank.  1 process: band_rank 0, band_world 1. */
     int32_t band_rank;
     int32_t band_world;
+    /* Sample sub-range: render only samples [sample_begin, sample_begin + sample_count) of the
+     * rays_per_pixel samples of each pixel (progressive accumulation into one film);
+     * sample_count == 0 means all of them. */
+    int32_t sample_begin;
+    int32_t sample_count;
     int32_t reserved;
     void* stream; /* hipStream_t to launch on; NULL = the null stream */
 } rt_render_opts;

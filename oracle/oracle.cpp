@@ -1420,7 +1420,9 @@ int oracle_render(const oracle_scene* s, const rt_camera_desc* cam, const rt_ren
                     if ((imgy / tile) % band_world != opts->band_rank) continue;
                     for (int x = x0; x < x1; x++) {
                         V3 rgb{0, 0, 0};
-                        for (int sample = 0; sample < spp; sample++) {
+                        const int s_first = opts->sample_count > 0 ? opts->sample_begin : 0;
+                        const int s_end = opts->sample_count > 0 ? opts->sample_begin + opts->sample_count : spp;
+                        for (int sample = s_first; sample < s_end; sample++) {
                             Rng rng;
                             rng.k0 = (uint32_t)((uint64_t)opts->seed & 0xffffffffu);
                             rng.k1 = (uint32_t)((uint64_t)opts->seed >> 32);

@@ -123,8 +123,8 @@ class RenderOpts(C.Structure):
     _fields_ = [
         ("seed", C.c_int64), ("rays_per_pixel", C.c_int32), ("max_ray_depth", C.c_int32),
         ("dx", C.c_int32), ("dy", C.c_int32), ("mode", C.c_int32),
-        ("band_rank", C.c_int32), ("band_world", C.c_int32), ("reserved", C.c_int32),
-        ("stream", C.c_void_p),
+        ("band_rank", C.c_int32), ("band_world", C.c_int32), ("sample_begin", C.c_int32),
+        ("sample_count", C.c_int32), ("reserved", C.c_int32), ("stream", C.c_void_p),
     ]
 
 

@@ -239,6 +239,8 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     const int world = o->band_world > 0 ? o->band_world : 1;
     const int rank = o->band_rank;
     if (rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "band_rank out of range");
+    if (o->sample_count < 0 || o->sample_begin < 0 || (o->sample_count > 0 && o->sample_begin + o->sample_count > o->rays_per_pixel))
+        return fail(RT_ERR_INVALID, "sample range outside [0, RaysPerPixel)");
     HIP_TRY(hipSetDevice(sc->device));
     DCamera cam;
     if (int rc = make_camera(*camera, cam)) return rc;
@@ -327,10 +329,12 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         return RT_OK;
     };
 
-    for (int s0 = 0; s0 < o->rays_per_pixel && rc == RT_OK;) {
+    const int s_first = o->sample_count > 0 ? o->sample_begin : 0;
+    const int s_end = o->sample_count > 0 ? o->sample_begin + o->sample_count : o->rays_per_pixel;
+    for (int s0 = s_first; s0 < s_end && rc == RT_OK;) {
         // a pass covers either all tiles for a run of samples, or a run of tiles for one sample
         int s_count = 1;
-        if (tiles_total <= tiles_per_launch) s_count = (int)std::min<int64_t>(o->rays_per_pixel - s0, tiles_per_launch / std::max<int64_t>(tiles_total, 1));
+        if (tiles_total <= tiles_per_launch) s_count = (int)std::min<int64_t>(s_end - s0, tiles_per_launch / std::max<int64_t>(tiles_total, 1));
         for (int64_t t0 = 0; t0 < tiles_total && rc == RT_OK; t0 += tiles_per_launch) {
             const int64_t nt = std::min(tiles_per_launch, tiles_total - t0);
             pass.sample_begin = s0;

@@ -749,9 +749,10 @@ def camera_desc(cam) -> abi.CameraDesc:
     return d
 
 
-def render_opts(o: RenderOptions, mode=abi.MODE_FAST, band_rank=0, band_world=1, stream=None) -> abi.RenderOpts:
+def render_opts(o: RenderOptions, mode=abi.MODE_FAST, band_rank=0, band_world=1, stream=None, sample_begin=0,
+                sample_count=0) -> abi.RenderOpts:
     return abi.RenderOpts(int(o.Seed), int(o.RaysPerPixel), int(o.MaxRayDepth), int(o.Dx), int(o.Dy), int(mode),
-                          int(band_rank), int(band_world), 0, stream)
+                          int(band_rank), int(band_world), int(sample_begin), int(sample_count), 0, stream)
 
 
 # ---- the render entry point -------------------------------------------------------------

@@ -111,7 +111,7 @@ def faces_from(vertices: np.ndarray, uv: np.ndarray, tris: np.ndarray) -> np.nda
 
 def scan_standin_mesh(level: int = 7, seed: int = 1234) -> np.ndarray:
     """Stand-in for the missing einstein photogrammetry scan: an icosphere displaced
-    radially by 4 octaves of value noise into a bust-like blob of radius ~70..100
+    radially by 4 octaves of value noise into a bust-like blob of radius ~85..125
     raw OBJ units, with per-vertex equirectangular UVs.  20*4**level faces
     (level 7: 327,680; level 8: 1,310,720)."""
     v, f = icosphere(level)
@@ -121,7 +121,7 @@ def scan_standin_mesh(level: int = 7, seed: int = 1234) -> np.ndarray:
         disp += amp * (value_noise3(v * freq + 17.0, seed + octave) - 0.5)
         amp *= 0.5
         freq *= 2.0
-    r = 85.0 * (1.0 + 0.35 * disp)
+    r = 105.0 * (1.0 + 0.35 * disp)
     # a "neck": squeeze below the equator so the silhouette is not a ball
     squeeze = 1.0 - 0.25 * np.clip(-v[:, 2] - 0.3, 0, 1)
     p = v * r[:, None]
