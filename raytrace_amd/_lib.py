@@ -6,7 +6,7 @@ import os
 from . import abi
 
 _LIB = None
-_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_hip.so")
+_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_hip.so")
 
 SYMBOLS = [
     "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",

@@ -118,8 +118,11 @@ RT_DEV float up32(double x) {  // float32 not below x
 
 // Traversal stack of (node, entry distance) pairs.  The first kLdsPairs pairs live in LDS
 // (this lane's column: dword i at lds[i * stride]); deeper pairs spill to private memory.
-constexpr int kLdsPairs = 12;
-constexpr int kSpillPairs = 28;  // 12 + 28 >= the builder's depth limit of 32 plus the root
+#ifndef RT_LDS_PAIRS
+#define RT_LDS_PAIRS 12
+#endif
+constexpr int kLdsPairs = RT_LDS_PAIRS;
+constexpr int kSpillPairs = 40 - RT_LDS_PAIRS;  // together >= the builder's depth limit of 32 plus the root
 
 struct PairStack {
     int32_t* lds;
@@ -150,7 +153,7 @@ struct PairStack {
 
 template <bool ANY_HIT>
 RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, double tmin, double tmax, int& prim, double& t_out,
-                              double& u_out, double& v_out, int32_t* lds, int stride) {
+                              double& u_out, double& v_out, int32_t* lds, int stride, VisitCounts& cnt) {
     FastRay f;
     if (!fast_setup(m, r, tmin, tmax, f)) return false;
     const FastNode* nodes = sc.fast_nodes + m.fast_off;
@@ -165,6 +168,7 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
     bool hit = false;
     for (;;) {
         const FastNode n = nodes[cur];
+        cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
         float tn[2];
         bool go[2];
 #pragma unroll
@@ -191,6 +195,7 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
                 for (int32_t q = 0; q < n.count[k]; q++) {
                     const double* p = pos + (int64_t)(first + q) * 9;
                     double t, u, v;
+                    cnt.prims++;
                     if (mt_core(r, ld3(p), ld3(p + 3), ld3(p + 6), 1e-8, tmin, tmax, t, u, v)) {
                         hit = true;
                         if (ANY_HIT) return true;

@@ -7,33 +7,33 @@
 
 namespace rt {
 
-// Which pixels a render pass covers and how path indices map to (pixel, sample).
+// Which pixels a render pass covers and how its threads map to (pixel, sample).
 struct PassDesc {
     int32_t dx, dy;
     int32_t band_rank, band_world;  // rows are cut into bands of 16; this process owns band b iff b % world == rank
     int32_t local_rows;             // image rows owned by this process
     int32_t tiles_x;                // 8x8 pixel tiles per row of tiles
     int32_t spp;                    // RaysPerPixel of the whole render
-    int32_t sample_begin, sample_count;  // samples handled by this pass
-    int64_t tile_begin;             // first 8x8 tile (in local tile order) of this pass
-    int64_t n_paths;                // tiles * 64 * sample_count
-    uint32_t seed_lo, seed_hi;
+    int32_t sample_begin, sample_count;  // sample indices handled by this pass (each thread loops over them)
     int32_t max_depth;
-    int32_t pad;
+    int64_t tile_begin;             // first 8x8 tile (in local tile order) of this pass
+    int64_t n_pixels;               // tiles * 64 = threads of the primary launch
+    uint32_t seed_lo, seed_hi;
 };
 
 struct Queues {
-    RayRec* rays;       // current generation
-    HitRec* hits;
-    RayRec* next;       // next generation (append)
-    SurfRec* surfs;     // lit surface points of this generation (append)
+    RayQ rays;      // generation being traced / children appended by k_shade
+    RayQ shade_ray; // rays whose hit needs Material.Resolve ...
+    HitQ shade_hit; // ... and their collisions (same index)
+    SurfQ surfs;    // lit surface points of this generation
     Counters* counters;
-    uint32_t next_capacity, surf_capacity;
+    uint32_t ray_capacity, shade_capacity, surf_capacity;
 };
 
-void launch_generate(const DCamera& cam, const PassDesc& pass, RayRec* rays, hipStream_t s);
-void launch_extend(const DScene& sc, const RayRec* rays, HitRec* hits, uint32_t n, int mode, hipStream_t s);
-void launch_shade(const DScene& sc, const PassDesc& pass, const Queues& q, uint32_t n, double* film, hipStream_t s);
+void launch_primary(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, int mode, bool mesh_only, double* film,
+                    hipStream_t s);
+void launch_trace(const DScene& sc, const Queues& q, uint32_t n, int mode, bool mesh_only, double* film, hipStream_t s);
+void launch_shade(const DScene& sc, const PassDesc& pass, const Queues& q, uint32_t n_upper, double* film, hipStream_t s);
 void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode, double* film, hipStream_t s);
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s);
 void launch_intersect_batch(const DScene& sc, const double* o, const double* d, uint64_t n, double tmin, double tmax, int mode,

@@ -1,10 +1,12 @@
 // HIP kernels of the wavefront path tracer (gfx950).
 //
-// One launch per stage and generation:
-//   k_generate  camera rays for a pass (8x8 pixel tiles x a run of sample indices)
-//   k_extend    closest hit of every queued ray: analytic shapes in float64, meshes by BVH walk
-//   k_shade     Material.Resolve: emission to the film, children appended to the next queue
-//               (wave64 ballot compaction), lit surface points appended for the light loop
+//   k_primary   one thread per pixel of a pass, looping over the pass's sample indices: camera ray
+//               -> closest hit -> misses counted, hits on emitting-only materials (Emitter,
+//               DebugUV, DebugNormal) summed in registers and added to the film once; every
+//               other hit is appended (wave64 ballot compaction) to the shade queue
+//   k_trace     the same for a queued generation of scattered rays, one ray per thread
+//   k_shade     Material.Resolve for the shade queue: children appended to the ray queue,
+//               lit surface points appended for the light loop
 //   k_direct    one thread per (surface point, light): occlusion ray + BRDF, added to the film
 //   k_resolve   film sums -> 8-bit RGBA exactly as renderPixel quantises (render.go:218-224)
 #include "kernels.h"
@@ -15,7 +17,16 @@
 namespace rt {
 
 constexpr int kBlock = 256;
-constexpr uint32_t kInvalidPixel = 0xFFFFFFFFu;
+// Traversal kernels run one wave per workgroup: waves of a tile that misses the mesh retire early and
+// a one-wave workgroup frees its slot (registers, LDS stack) at once instead of waiting for its slowest sibling.
+#ifndef RT_TRACE_BLOCK
+#define RT_TRACE_BLOCK 64
+#endif
+constexpr int kTraceBlock = RT_TRACE_BLOCK;
+// Waves per SIMD the traversal kernels are compiled for in fast mode (caps VGPRs at 512 / waves).
+#ifndef RT_FAST_WAVES
+#define RT_FAST_WAVES 4
+#endif
 
 // ---- scene level intersection ---------------------------------------------------------------
 
@@ -23,6 +34,10 @@ struct SceneHit {
     int node, prim;
     Col c;
 };
+
+template <int MODE>
+RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, VisitCounts& cnt,
+                              int32_t* lds, int stride);
 
 // Shape.Collide for one top-level shape.  Transformed shapes (shape_transformed_shape.go:26-57)
 // are unwound iteratively: the ray goes through each inverse transform (direction not
@@ -52,19 +67,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
         case RT_SHAPE_QUAD: hit = quad_collide(sc.quads[index], r, tmin, tmax, c); break;
         case RT_SHAPE_CYLINDER: hit = cylinder_collide(sc.cylinders[index], r, tmin, tmax, c); break;
         case RT_SHAPE_TRIANGLE: hit = tri_collide(sc.tris[index], r, tmin, tmax, c); break;
-        case RT_SHAPE_MESH: {
-            const DMesh& m = sc.meshes[index];
-            double t, u, v;
-            int p = 0;
-            if (MODE == RT_MODE_REFERENCE) hit = mesh_collide_ref(sc, m, r, tmin, tmax, p, t, u, v, cnt);
-            else hit = mesh_collide_fast<false>(sc, m, r, tmin, tmax, p, t, u, v, lds, stride);
-            if (hit) {
-                const double* pos = sc.prim_pos + (m.prim_off + p) * 9;
-                prim = sc.prim_face[m.prim_off + p];
-                face_finish(r, ld3(pos), ld3(pos + 3), ld3(pos + 6), sc.face_uv + (m.face_off + prim) * 6, t, u, v, c);
-            }
-            break;
-        }
+        case RT_SHAPE_MESH: hit = mesh_node_collide<MODE>(sc, index, r, tmin, tmax, c, prim, cnt, lds, stride); break;
         default: break;
     }
     if (hit) {
@@ -77,8 +80,27 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
     return hit;
 }
 
-// The node loop of tracePath (render.go:155-169).
+// Mesh.Collide for a top-level (untransformed) mesh node, attributes of the winning face included.
 template <int MODE>
+RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, VisitCounts& cnt,
+                              int32_t* lds, int stride) {
+    const DMesh& m = sc.meshes[index];
+    double t, u, v;
+    int p = 0;
+    bool hit;
+    if (MODE == RT_MODE_REFERENCE) hit = mesh_collide_ref(sc, m, r, tmin, tmax, p, t, u, v, cnt);
+    else hit = mesh_collide_fast<false>(sc, m, r, tmin, tmax, p, t, u, v, lds, stride, cnt);
+    if (hit) {
+        const double* pos = sc.prim_pos + (m.prim_off + p) * 9;
+        prim = sc.prim_face[m.prim_off + p];
+        face_finish(r, ld3(pos), ld3(pos + 3), ld3(pos + 6), sc.face_uv + (m.face_off + prim) * 6, t, u, v, c);
+    }
+    return hit;
+}
+
+// The node loop of tracePath (render.go:155-169).  MESH_ONLY: the host has checked that every
+// node is a plain mesh, so the other shapes' code (and its registers) is left out.
+template <int MODE, bool MESH_ONLY = false>
 RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, int32_t* lds,
                           int stride) {
     double min_dist = tmax;
@@ -87,7 +109,9 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
         const DNode nd = sc.nodes[i];
         Col c;
         int prim;
-        if (shape_collide<MODE>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, lds, stride) && c.t < min_dist) {
+        const bool got = MESH_ONLY ? mesh_node_collide<MODE>(sc, nd.index, r, tmin, min_dist, c, prim, cnt, lds, stride)
+                                   : shape_collide<MODE>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, lds, stride);
+        if (got && c.t < min_dist) {
             min_dist = c.t;
             h.c = c;
             h.node = i;
@@ -111,7 +135,7 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
         if (MODE == RT_MODE_FAST && nd.kind == RT_SHAPE_MESH) {
             double t, u, v;
             int p;
-            if (mesh_collide_fast<true>(sc, sc.meshes[nd.index], r, kEps, dist, p, t, u, v, lds, stride)) return true;
+            if (mesh_collide_fast<true>(sc, sc.meshes[nd.index], r, kEps, dist, p, t, u, v, lds, stride, cnt)) return true;
             continue;
         }
         Col c;
@@ -183,9 +207,22 @@ RT_DEV uint32_t wave_append(unsigned int* counter, bool want) {
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-RT_DEV void wave_count(unsigned long long* counter, bool flag) {
-    const unsigned long long mask = __ballot(flag);
-    if (mask != 0 && (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1) atomicAdd(counter, (unsigned long long)__popcll(mask));
+RT_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Adds per-lane tallies to the RenderStats counters, one atomic per wave and counter.
+RT_DEV void wave_tally(Counters* c, uint32_t total, uint32_t left, uint32_t exceeded) {
+    total = wave_sum(total);
+    left = wave_sum(left);
+    exceeded = wave_sum(exceeded);
+    if ((threadIdx.x & 63) == 0) {
+        if (total) atomicAdd(&c->total, (unsigned long long)total);
+        if (left) atomicAdd(&c->left, (unsigned long long)left);
+        if (exceeded) atomicAdd(&c->exceeded, (unsigned long long)exceeded);
+    }
 }
 
 RT_DEV void film_add(double* film, uint32_t pixel, V3 v) {
@@ -195,165 +232,235 @@ RT_DEV void film_add(double* film, uint32_t pixel, V3 v) {
     if (v.z != 0) atomicAdd(f + 2, v.z);
 }
 
+RT_DEV bool terminal_kind(int kind) { return kind == RT_MAT_EMITTER || kind == RT_MAT_DEBUG_UV || kind == RT_MAT_DEBUG_NORMAL; }
+
+// Resolve of the three materials that only emit (material_emitter.go:22-25,
+// material_debug_uv.go:18-28, material_debug_normal.go:45-81).
+RT_DEV V3 terminal_emission(const DScene& sc, const rt_material& m, const Col& c, V3 rad) {
+    if (m.kind == RT_MAT_EMITTER) return texture_at(sc, m.texture, c.u, c.v) * rad;
+    if (m.kind == RT_MAT_DEBUG_UV) {
+        if (c.u < 0.0 || c.u > 1.0) return mk(1.0, 0.0, 0.0);
+        return mk(go_min(go_max(c.u, 0.0), 1.0), go_min(go_max(c.v, 0.0), 1.0), 0.5);
+    }
+    V3 n = c.normal;
+    double len = sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+    if (!(len > 0)) len = 1;
+    double r = 0.5 * (n.x / len + 1.0), g = 0.5 * (n.y / len + 1.0), b = 0.5 * (n.z / len + 1.0);
+    r = r < 0 ? 0 : (r > 1 ? 1 : r);
+    g = g < 0 ? 0 : (g > 1 ? 1 : g);
+    b = b < 0 ? 0 : (b > 1 ? 1 : b);
+    return mk(r, g, b);
+}
+
+struct PathState {
+    V3 rad;
+    uint32_t pixel, sample, path, depth_n;
+};
+
+RT_DEV void put_shade(const Queues& q, uint32_t slot, const Ray& r, const PathState& ps, const SceneHit& h) {
+    q.shade_ray.o[0][slot] = r.o.x; q.shade_ray.o[1][slot] = r.o.y; q.shade_ray.o[2][slot] = r.o.z;
+    q.shade_ray.d[0][slot] = r.d.x; q.shade_ray.d[1][slot] = r.d.y; q.shade_ray.d[2][slot] = r.d.z;
+    q.shade_ray.rad[0][slot] = ps.rad.x; q.shade_ray.rad[1][slot] = ps.rad.y; q.shade_ray.rad[2][slot] = ps.rad.z;
+    q.shade_ray.pixel[slot] = ps.pixel;
+    q.shade_ray.sample[slot] = ps.sample;
+    q.shade_ray.path[slot] = ps.path;
+    q.shade_ray.depth_n[slot] = ps.depth_n;
+    q.shade_hit.node[slot] = h.node;
+    q.shade_hit.prim[slot] = h.prim;
+    q.shade_hit.t[slot] = h.c.t;
+    q.shade_hit.at[0][slot] = h.c.at.x; q.shade_hit.at[1][slot] = h.c.at.y; q.shade_hit.at[2][slot] = h.c.at.z;
+    q.shade_hit.nrm[0][slot] = h.c.normal.x; q.shade_hit.nrm[1][slot] = h.c.normal.y; q.shade_hit.nrm[2][slot] = h.c.normal.z;
+    q.shade_hit.uv[0][slot] = h.c.u; q.shade_hit.uv[1][slot] = h.c.v;
+}
+
+// The first half of tracePath for one ray (render.go:143-173): NaN guard, closest hit, miss.
+// Returns 0 = nothing further (invalid ray or miss), 1 = hit an emitting-only material
+// (`emission` set), 2 = hit needs Material.Resolve (`h` set).
+template <int MODE, bool MESH_ONLY>
+RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, uint32_t& n_left, int32_t* lds, int stride) {
+    if (bad3(r.o) || bad3(r.d)) return 0;  // render.go:147-150
+    VisitCounts cnt{0, 0};
+    if (!scene_closest<MODE, MESH_ONLY>(sc, r, kEps, kMaxFloat, h, cnt, lds, stride)) {
+        n_left++;
+        return 0;
+    }
+    const rt_material& m = sc.materials[sc.nodes[h.node].material];
+    if (terminal_kind(m.kind)) {
+        emission = terminal_emission(sc, m, h.c, rad);
+        return 1;
+    }
+    return 2;
+}
+
 // ---- kernels -----------------------------------------------------------------------------------
 
-// renderPixel's sample loop body up to camera.Cast (render.go:197-214) for one pass.
-__global__ void __launch_bounds__(kBlock) k_generate(DCamera cam, PassDesc pass, RayRec* __restrict__ rays) {
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= pass.n_paths) return;
+// renderPixel (render.go:186-217) for one pass: thread = pixel (8x8 tiles, one tile per wave),
+// loop = the pass's sample indices.
+template <int MODE, bool MESH_ONLY>
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_primary(DScene sc, DCamera cam, PassDesc pass, Queues q, double* __restrict__ film) {
+    __shared__ int32_t lds[MODE == RT_MODE_FAST ? 2 * kLdsPairs * kTraceBlock : 1];
+    const int64_t g = (int64_t)blockIdx.x * kTraceBlock + threadIdx.x;
     const int p = (int)(g & 63);
-    const int64_t wave = g >> 6;
-    const int s = pass.sample_begin + (int)(wave % pass.sample_count);
-    const int64_t tile = pass.tile_begin + wave / pass.sample_count;
+    const int64_t tile = pass.tile_begin + (g >> 6);
     const int lx = (int)(tile % pass.tiles_x) * 8 + (p & 7);
     const int ly = (int)(tile / pass.tiles_x) * 8 + (p >> 3);
-    RayRec rec;
-    rec.pixel = kInvalidPixel;
-    rec.sample = (uint32_t)s;
-    rec.path = 1;
-    rec.depth_n = 0;
     const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
-    if (lx < pass.dx && ly < pass.local_rows && row < pass.dy) {
-        const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
-        Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(y * pass.dx + lx), (uint32_t)s, 1u, 0u};
-        double fs, ft;
-        if (pass.spp == 1) {  // render.go:202-210
-            fs = ((double)lx + 0.5) / (double)pass.dx;
-            ft = ((double)y + 0.5) / (double)pass.dy;
-        } else {
-            fs = ((double)lx + rng.float64()) / (double)pass.dx;
-            ft = ((double)y + rng.float64()) / (double)pass.dy;
+    const bool live = g < pass.n_pixels && lx < pass.dx && ly < pass.local_rows && row < pass.dy;
+    const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
+    const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
+    V3 acc = mk(0, 0, 0);
+    uint32_t n_total = 0, n_left = 0;
+    for (int k = 0; k < pass.sample_count; k++) {
+        const int s = pass.sample_begin + k;
+        bool want = false;
+        Ray r;
+        SceneHit h;
+        PathState ps;
+        if (live) {
+            Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(y * pass.dx + lx), (uint32_t)s, 1u, 0u};
+            double fs, ft;
+            if (pass.spp == 1) {  // render.go:202-210
+                fs = ((double)lx + 0.5) / (double)pass.dx;
+                ft = ((double)y + 0.5) / (double)pass.dy;
+            } else {
+                fs = ((double)lx + rng.float64()) / (double)pass.dx;
+                ft = ((double)y + rng.float64()) / (double)pass.dy;
+            }
+            r = camera_cast(cam, fs, ft, rng);
+            n_total++;
+            V3 em;
+            const int what = trace_one<MODE, MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, lds + threadIdx.x, kTraceBlock);
+            if (what == 1) acc = acc + em;
+            want = what == 2;
+            ps.rad = mk(1, 1, 1);
+            ps.pixel = pixel;
+            ps.sample = (uint32_t)s;
+            ps.path = 1;
+            ps.depth_n = rng.n;
         }
-        Ray r = camera_cast(cam, fs, ft, rng);
-        st3(rec.o, r.o);
-        st3(rec.d, r.d);
-        rec.rad[0] = rec.rad[1] = rec.rad[2] = 1.0;
-        rec.pixel = (uint32_t)(row * pass.dx + lx);
-        rec.depth_n = rng.n;
-    } else {
-        rec.o[0] = rec.o[1] = rec.o[2] = 0;
-        rec.d[0] = rec.d[1] = rec.d[2] = 0;
-        rec.rad[0] = rec.rad[1] = rec.rad[2] = 0;
+        const uint32_t slot = wave_append(&q.counters->shade_count, want);
+        if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
     }
-    rays[g] = rec;
+    wave_tally(q.counters, n_total, n_left, 0);
+    if (live) {  // this launch is the only writer of this pixel while it runs: plain read-modify-write
+        double* f = film + (size_t)pixel * 3;
+        if (acc.x != 0) f[0] += acc.x;
+        if (acc.y != 0) f[1] += acc.y;
+        if (acc.z != 0) f[2] += acc.z;
+    }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_extend(DScene sc, const RayRec* __restrict__ rays, HitRec* __restrict__ hits, uint32_t n) {
-    __shared__ int32_t lds[MODE == RT_MODE_FAST ? 2 * kLdsPairs * kBlock : 1];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const RayRec rec = rays[i];
-    HitRec h;
-    h.node = -1;
-    h.prim = 0;
-    h.t = 0;
-    if (rec.pixel != kInvalidPixel) {
-        Ray r{ld3(rec.o), ld3(rec.d)};
-        SceneHit sh;
-        VisitCounts cnt{0, 0};
-        if (!bad3(r.o) && !bad3(r.d) && scene_closest<MODE>(sc, r, kEps, kMaxFloat, sh, cnt, lds + threadIdx.x, kBlock)) {
-            h.node = sh.node;
-            h.prim = sh.prim;
-            h.t = sh.c.t;
-            st3(h.at, sh.c.at);
-            st3(h.normal, sh.c.normal);
-            h.uv[0] = sh.c.u;
-            h.uv[1] = sh.c.v;
-        }
+template <int MODE, bool MESH_ONLY>
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_trace(DScene sc, Queues q, uint32_t n, double* __restrict__ film) {
+    __shared__ int32_t lds[MODE == RT_MODE_FAST ? 2 * kLdsPairs * kTraceBlock : 1];
+    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
+    const bool live = i < n;
+    bool want = false;
+    uint32_t n_left = 0;
+    Ray r;
+    SceneHit h;
+    PathState ps;
+    if (live) {
+        r.o = mk(q.rays.o[0][i], q.rays.o[1][i], q.rays.o[2][i]);
+        r.d = mk(q.rays.d[0][i], q.rays.d[1][i], q.rays.d[2][i]);
+        ps.rad = mk(q.rays.rad[0][i], q.rays.rad[1][i], q.rays.rad[2][i]);
+        ps.pixel = q.rays.pixel[i];
+        ps.sample = q.rays.sample[i];
+        ps.path = q.rays.path[i];
+        ps.depth_n = q.rays.depth_n[i];
+        V3 em;
+        const int what = trace_one<MODE, MESH_ONLY>(sc, r, ps.rad, h, em, n_left, lds + threadIdx.x, kTraceBlock);
+        if (what == 1) film_add(film, ps.pixel, em);
+        want = what == 2;
     }
-    hits[i] = h;
+    const uint32_t slot = wave_append(&q.counters->shade_count, want);
+    if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
+    wave_tally(q.counters, live ? 1u : 0u, n_left, 0);
 }
 
-// tracePath after the intersection (render.go:143-182): counters, Material.Resolve, emission,
-// children.  ComputeDirectLighting is deferred to k_direct through a SurfRec.
-__global__ void __launch_bounds__(kBlock) k_shade(DScene sc, PassDesc pass, Queues q, uint32_t n, double* __restrict__ film) {
+// The second half of tracePath (render.go:174-182) for hits that need it: Material.Resolve,
+// children appended to the ray queue, lit points appended for k_direct.
+__global__ void __launch_bounds__(kBlock) k_shade(DScene sc, PassDesc pass, Queues q, double* __restrict__ film) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool in_range = i < n;
-    RayRec rec;
-    rec.pixel = kInvalidPixel;
-    if (in_range) rec = q.rays[i];
-    const bool live = in_range && rec.pixel != kInvalidPixel;
-    bool left = false;
+    const uint32_t n = min(q.counters->shade_count, q.shade_capacity);
+    if (blockIdx.x * kBlock >= n) return;  // whole block beyond the queue (the grid is an upper bound)
+    const bool live = i < n;
     int n_child = 0;
-    int n_cut = 0;       // children beyond MaxRayDepth: counted, not traced (render.go:151-154)
-    int n_counted = 0;   // children that only bump TotalRays (cut or invalid)
+    uint32_t n_cut = 0, n_counted = 0;  // children beyond MaxRayDepth or invalid: counted, never traced
     bool want_surf = false;
-    RayRec child[2];
-    SurfRec surf;
-    Ray r{ld3(rec.o), ld3(rec.d)};
-    const bool valid = live && !bad3(r.o) && !bad3(r.d);  // render.go:147-150
-    if (valid) {
-        const HitRec h = q.hits[i];
-        if (h.node < 0) {
-            left = true;
-        } else {
-            const rt_material m = sc.materials[sc.nodes[h.node].material];
-            Col c;
-            c.t = h.t;
-            c.at = ld3(h.at);
-            c.normal = ld3(h.normal);
-            c.u = h.uv[0];
-            c.v = h.uv[1];
-            const uint32_t x = rec.pixel % (uint32_t)pass.dx, row = rec.pixel / (uint32_t)pass.dx;
-            const uint32_t depth = rec.depth_n >> 24;
-            Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(pass.dy - 1 - (int)row) * (uint32_t)pass.dx + x, rec.sample, rec.path,
-                    rec.depth_n & 0xFFFFFFu};
-            Scatter sct;
-            resolve(sc, m, r.d, ld3(rec.rad), c, rng, sct);
-            film_add(film, rec.pixel, sct.emission);
-            for (int k = 0; k < sct.n; k++) {
-                const bool bad = bad3(c.at) || bad3(sct.dir[k]);
-                if (bad) { n_counted++; continue; }
-                if ((int)depth + 1 > pass.max_depth) { n_counted++; n_cut++; continue; }
-                RayRec& ch = child[n_child++];
-                st3(ch.o, c.at);
-                st3(ch.d, sct.dir[k]);
-                st3(ch.rad, sct.rad[k]);
-                ch.pixel = rec.pixel;
-                ch.sample = rec.sample;
-                ch.path = rec.path * 2u + (uint32_t)k;
-                ch.depth_n = (depth + 1u) << 24;
-            }
-            if (sc.n_lights > 0 && (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC)) {
-                want_surf = true;
-                V3 nn = unit(c.normal);
-                V3 wo = unit(r.d * -1.0);  // s.outgoing.Unit() (material_metal.go:59)
-                surf.inside = 0;
-                V3 alb = mk(0, 0, 0);
-                if (m.kind == RT_MAT_LAMBERTIAN) alb = texture_at(sc, m.texture, c.u, c.v);
-                else if (m.kind == RT_MAT_METAL) alb = ld3(m.albedo);
-                else if (!(dot(wo, nn) > 0)) { surf.inside = 1; nn = nn * -1.0; }  // material_dielectric.go:112-120
-                st3(surf.p, c.at);
-                st3(surf.n, nn);
-                st3(surf.wo, wo);
-                st3(surf.albedo, alb);
-                surf.pixel = rec.pixel;
-                surf.node = h.node;
-                surf.material = sc.nodes[h.node].material;
-            }
+    V3 child_d[2], child_rad[2];
+    uint32_t child_path[2];
+    V3 at = mk(0, 0, 0), s_n = mk(0, 0, 0), s_wo = mk(0, 0, 0), s_alb = mk(0, 0, 0);
+    uint32_t pixel = 0, sample = 0, depth = 0;
+    int node = 0, mat_index = 0, inside = 0;
+    if (live) {
+        const Ray r{mk(q.shade_ray.o[0][i], q.shade_ray.o[1][i], q.shade_ray.o[2][i]),
+                    mk(q.shade_ray.d[0][i], q.shade_ray.d[1][i], q.shade_ray.d[2][i])};
+        const V3 rad = mk(q.shade_ray.rad[0][i], q.shade_ray.rad[1][i], q.shade_ray.rad[2][i]);
+        pixel = q.shade_ray.pixel[i];
+        sample = q.shade_ray.sample[i];
+        const uint32_t path = q.shade_ray.path[i];
+        const uint32_t depth_n = q.shade_ray.depth_n[i];
+        depth = depth_n >> 24;
+        node = q.shade_hit.node[i];
+        mat_index = sc.nodes[node].material;
+        const rt_material m = sc.materials[mat_index];
+        Col c;
+        c.t = q.shade_hit.t[i];
+        c.at = mk(q.shade_hit.at[0][i], q.shade_hit.at[1][i], q.shade_hit.at[2][i]);
+        c.normal = mk(q.shade_hit.nrm[0][i], q.shade_hit.nrm[1][i], q.shade_hit.nrm[2][i]);
+        c.u = q.shade_hit.uv[0][i];
+        c.v = q.shade_hit.uv[1][i];
+        at = c.at;
+        const uint32_t x = pixel % (uint32_t)pass.dx, row = pixel / (uint32_t)pass.dx;
+        Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(pass.dy - 1 - (int)row) * (uint32_t)pass.dx + x, sample, path, depth_n & 0xFFFFFFu};
+        Scatter sct;
+        resolve(sc, m, r.d, rad, c, rng, sct);
+        film_add(film, pixel, sct.emission);
+        for (int k = 0; k < sct.n; k++) {
+            if (bad3(c.at) || bad3(sct.dir[k])) { n_counted++; continue; }                      // render.go:147-150
+            if ((int)depth + 1 > pass.max_depth) { n_counted++; n_cut++; continue; }            // render.go:151-154
+            child_d[n_child] = sct.dir[k];
+            child_rad[n_child] = sct.rad[k];
+            child_path[n_child] = path * 2u + (uint32_t)k;
+            n_child++;
+        }
+        if (sc.n_lights > 0 && (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC)) {
+            want_surf = true;
+            s_n = unit(c.normal);
+            s_wo = unit(r.d * -1.0);  // s.outgoing.Unit() (material_metal.go:59)
+            if (m.kind == RT_MAT_LAMBERTIAN) s_alb = texture_at(sc, m.texture, c.u, c.v);
+            else if (m.kind == RT_MAT_METAL) s_alb = ld3(m.albedo);
+            else if (!(dot(s_wo, s_n) > 0)) { inside = 1; s_n = s_n * -1.0; }  // material_dielectric.go:112-120
         }
     }
-    // counters (render.go:143, 152, 171), one atomic per wave
-    {
-        const unsigned long long m_live = __ballot(live), m_left = __ballot(left);
-        const unsigned long long c1 = __ballot(n_counted >= 1), c2 = __ballot(n_counted >= 2);
-        const unsigned long long x1 = __ballot(n_cut >= 1), x2 = __ballot(n_cut >= 2);
-        if ((threadIdx.x & 63) == 0) {
-            const unsigned long long tot = __popcll(m_live) + __popcll(c1) + __popcll(c2);
-            if (tot) atomicAdd(&q.counters->total, tot);
-            if (m_left) atomicAdd(&q.counters->left, (unsigned long long)__popcll(m_left));
-            const unsigned long long ex = __popcll(x1) + __popcll(x2);
-            if (ex) atomicAdd(&q.counters->exceeded, ex);
-        }
-    }
+    wave_tally(q.counters, n_counted, 0, n_cut);
     // wave64 ballot compaction of the surviving paths into the next generation
-    const uint32_t s0 = wave_append(&q.counters->next_count, n_child >= 1);
-    const uint32_t s1 = wave_append(&q.counters->next_count, n_child >= 2);
-    if (n_child >= 1 && s0 < q.next_capacity) q.next[s0] = child[0];
-    if (n_child >= 2 && s1 < q.next_capacity) q.next[s1] = child[1];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const bool want = n_child > k;
+        const uint32_t slot = wave_append(&q.counters->next_count, want);
+        if (want && slot < q.ray_capacity) {
+            q.rays.o[0][slot] = at.x; q.rays.o[1][slot] = at.y; q.rays.o[2][slot] = at.z;
+            q.rays.d[0][slot] = child_d[k].x; q.rays.d[1][slot] = child_d[k].y; q.rays.d[2][slot] = child_d[k].z;
+            q.rays.rad[0][slot] = child_rad[k].x; q.rays.rad[1][slot] = child_rad[k].y; q.rays.rad[2][slot] = child_rad[k].z;
+            q.rays.pixel[slot] = pixel;
+            q.rays.sample[slot] = sample;
+            q.rays.path[slot] = child_path[k];
+            q.rays.depth_n[slot] = (depth + 1u) << 24;
+        }
+    }
     const uint32_t ss = wave_append(&q.counters->surf_count, want_surf);
-    if (want_surf && ss < q.surf_capacity) q.surfs[ss] = surf;
+    if (want_surf && ss < q.surf_capacity) {
+        q.surfs.p[0][ss] = at.x; q.surfs.p[1][ss] = at.y; q.surfs.p[2][ss] = at.z;
+        q.surfs.n[0][ss] = s_n.x; q.surfs.n[1][ss] = s_n.y; q.surfs.n[2][ss] = s_n.z;
+        q.surfs.wo[0][ss] = s_wo.x; q.surfs.wo[1][ss] = s_wo.y; q.surfs.wo[2][ss] = s_wo.z;
+        q.surfs.albedo[0][ss] = s_alb.x; q.surfs.albedo[1][ss] = s_alb.y; q.surfs.albedo[2][ss] = s_alb.z;
+        q.surfs.pixel[ss] = pixel;
+        q.surfs.node[ss] = node;
+        q.surfs.material[ss] = mat_index;
+        q.surfs.inside[ss] = inside;
+    }
 }
 
 // ComputeDirectLighting's loop body for one (surface point, light) pair
@@ -363,36 +470,43 @@ __global__ void __launch_bounds__(kBlock) k_direct(DScene sc, Queues q, uint32_t
     __shared__ int32_t lds[MODE == RT_MODE_FAST ? 2 * kLdsPairs * kBlock : 1];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < n_surf;
-    wave_count(&q.counters->shadow, live);
+    {
+        const unsigned long long mask = __ballot(live);
+        if (mask != 0 && (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1) atomicAdd(&q.counters->shadow, (unsigned long long)__popcll(mask));
+    }
     if (!live) return;
-    const SurfRec s = q.surfs[i];
     const rt_light L = sc.lights[blockIdx.y];
-    const rt_material m = sc.materials[s.material];
-    const V3 p = ld3(s.p), n = ld3(s.n);
+    const rt_material m = sc.materials[q.surfs.material[i]];
+    const V3 p = mk(q.surfs.p[0][i], q.surfs.p[1][i], q.surfs.p[2][i]);
+    const V3 n = mk(q.surfs.n[0][i], q.surfs.n[1][i], q.surfs.n[2][i]);
     V3 dir = ld3(L.position) - p;  // PointLight.Sample, light.go:29-35
     const double dist = length(dir);
     dir = dir / dist;
     const V3 wi = m.kind == RT_MAT_LAMBERTIAN ? dir : unit(dir);
     Ray sh{p + n * kEps, wi};
-    if (scene_occluded<MODE>(sc, sh, dist, s.node, lds + threadIdx.x, kBlock)) return;
+    if (scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], lds + threadIdx.x, kBlock)) return;
     V3 contrib;
     if (m.kind == RT_MAT_LAMBERTIAN) {
         const double ndl = go_max(0, dot(n, dir));
-        contrib = (ld3(s.albedo) * ld3(L.intensity)) * ndl;
-    } else if (m.kind == RT_MAT_METAL) {
-        const V3 val = mf_evaluate(m.fuzz, ld3(m.albedo), ld3(s.wo), wi, n);
-        const double ct = go_max(0, dot(n, wi));
-        contrib = (ld3(L.intensity) * val) * ct;
+        const V3 alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
+        contrib = (alb * ld3(L.intensity)) * ndl;
     } else {
-        double eta_i = m.ior_exterior, eta_t = m.ior_interior;
-        if (s.inside) { const double tmp = eta_i; eta_i = eta_t; eta_t = tmp; }
-        const double cos_i = go_max(0, dot(wi, n));
-        const double fresnel = reflectance(cos_i, eta_i, eta_t);
-        const V3 val = mf_evaluate(m.roughness, mk(1, 1, 1), ld3(s.wo), wi, n) * fresnel;
-        const double ct = go_max(0, dot(n, wi));
-        contrib = (ld3(L.intensity) * val) * ct;
+        const V3 wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
+        if (m.kind == RT_MAT_METAL) {
+            const V3 val = mf_evaluate(m.fuzz, ld3(m.albedo), wo, wi, n);
+            const double ct = go_max(0, dot(n, wi));
+            contrib = (ld3(L.intensity) * val) * ct;
+        } else {
+            double eta_i = m.ior_exterior, eta_t = m.ior_interior;
+            if (q.surfs.inside[i]) { const double tmp = eta_i; eta_i = eta_t; eta_t = tmp; }
+            const double cos_i = go_max(0, dot(wi, n));
+            const double fresnel = reflectance(cos_i, eta_i, eta_t);
+            const V3 val = mf_evaluate(m.roughness, mk(1, 1, 1), wo, wi, n) * fresnel;
+            const double ct = go_max(0, dot(n, wi));
+            contrib = (ld3(L.intensity) * val) * ct;
+        }
     }
-    film_add(film, s.pixel, contrib);
+    film_add(film, q.surfs.pixel[i], contrib);
 }
 
 // renderPixel's quantisation (render.go:218-224).
@@ -454,22 +568,34 @@ __global__ void __launch_bounds__(kBlock) k_cast_batch(DCamera cam, const double
 
 static inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-void launch_generate(const DCamera& cam, const PassDesc& pass, RayRec* rays, hipStream_t s) {
-    if (pass.n_paths == 0) return;
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for((uint64_t)pass.n_paths)), dim3(kBlock), 0, s, cam, pass, rays);
+void launch_primary(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, int mode, bool mesh_only, double* film,
+                    hipStream_t s) {
+    if (pass.n_pixels == 0 || pass.sample_count == 0) return;
+    const dim3 grid((unsigned)(((uint64_t)pass.n_pixels + kTraceBlock - 1) / kTraceBlock)), block(kTraceBlock);
+    if (mode == RT_MODE_REFERENCE) {
+        if (mesh_only) hipLaunchKernelGGL((k_primary<RT_MODE_REFERENCE, true>), grid, block, 0, s, sc, cam, pass, q, film);
+        else hipLaunchKernelGGL((k_primary<RT_MODE_REFERENCE, false>), grid, block, 0, s, sc, cam, pass, q, film);
+    } else {
+        if (mesh_only) hipLaunchKernelGGL((k_primary<RT_MODE_FAST, true>), grid, block, 0, s, sc, cam, pass, q, film);
+        else hipLaunchKernelGGL((k_primary<RT_MODE_FAST, false>), grid, block, 0, s, sc, cam, pass, q, film);
+    }
 }
 
-void launch_extend(const DScene& sc, const RayRec* rays, HitRec* hits, uint32_t n, int mode, hipStream_t s) {
+void launch_trace(const DScene& sc, const Queues& q, uint32_t n, int mode, bool mesh_only, double* film, hipStream_t s) {
     if (n == 0) return;
-    if (mode == RT_MODE_REFERENCE)
-        hipLaunchKernelGGL(k_extend<RT_MODE_REFERENCE>, dim3(blocks_for(n)), dim3(kBlock), 0, s, sc, rays, hits, n);
-    else
-        hipLaunchKernelGGL(k_extend<RT_MODE_FAST>, dim3(blocks_for(n)), dim3(kBlock), 0, s, sc, rays, hits, n);
+    const dim3 grid((n + kTraceBlock - 1) / kTraceBlock), block(kTraceBlock);
+    if (mode == RT_MODE_REFERENCE) {
+        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true>), grid, block, 0, s, sc, q, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, false>), grid, block, 0, s, sc, q, n, film);
+    } else {
+        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, true>), grid, block, 0, s, sc, q, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false>), grid, block, 0, s, sc, q, n, film);
+    }
 }
 
-void launch_shade(const DScene& sc, const PassDesc& pass, const Queues& q, uint32_t n, double* film, hipStream_t s) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(n)), dim3(kBlock), 0, s, sc, pass, q, n, film);
+void launch_shade(const DScene& sc, const PassDesc& pass, const Queues& q, uint32_t n_upper, double* film, hipStream_t s) {
+    if (n_upper == 0) return;
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(n_upper)), dim3(kBlock), 0, s, sc, pass, q, film);
 }
 
 void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode, double* film, hipStream_t s) {

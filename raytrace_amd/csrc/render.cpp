@@ -1,0 +1,338 @@
+// The wavefront render loop: replacement for the body of renderScene (phys/render.go:285-349).
+//
+// The reference hands 16x16 tiles to NumCPU goroutines, each of which recurses through
+// tracePath per sample.  Here the image (this process's row bands of it) is cut into passes of
+// at most `q` paths; a pass is one k_primary launch (pixel per thread, sample loop inside) and
+// then, only while some hit needs Material.Resolve, generations of k_shade / k_direct / k_trace.
+// A scene whose materials all just emit (the scan configuration: Emitter + image texture) never
+// leaves k_primary and is rendered without a single host synchronisation per pass.
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+#include "host_common.h"
+
+namespace rt {
+
+struct WorkBuffers {
+    DeviceBuffers mem;
+    uint32_t q = 0;  // paths per launch at most
+    Queues queues{};
+    RayQ pool{};     // overflow stack for generations that outgrow q (Dielectric's two children)
+    uint64_t pool_capacity = 0;
+    void* pool_base = nullptr;
+    uint8_t* rgba = nullptr;
+    size_t rgba_bytes = 0;
+    double* film = nullptr;
+    size_t film_doubles = 0;
+};
+
+void destroy_work(WorkBuffers* w) {
+    if (!w) return;
+    if (w->pool_base) (void)hipFree(w->pool_base);
+    if (w->rgba) (void)hipFree(w->rgba);
+    if (w->film) (void)hipFree(w->film);
+    delete w;
+}
+
+namespace {
+
+size_t env_size(const char* name, size_t fallback) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return fallback;
+    return (size_t)std::strtoull(v, nullptr, 10);
+}
+
+// Carve structure-of-arrays views out of one allocation of cap * bytes-per-element.
+void carve(RayQ& r, void* base, size_t cap) {
+    char* p = static_cast<char*>(base);
+    for (int k = 0; k < 3; k++) { r.o[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    for (int k = 0; k < 3; k++) { r.d[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    for (int k = 0; k < 3; k++) { r.rad[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    r.pixel = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+    r.sample = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+    r.path = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+    r.depth_n = reinterpret_cast<uint32_t*>(p);
+}
+void carve(HitQ& h, void* base, size_t cap) {
+    char* p = static_cast<char*>(base);
+    h.t = reinterpret_cast<double*>(p); p += cap * 8;
+    for (int k = 0; k < 3; k++) { h.at[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    for (int k = 0; k < 3; k++) { h.nrm[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    for (int k = 0; k < 2; k++) { h.uv[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    h.node = reinterpret_cast<int32_t*>(p); p += cap * 4;
+    h.prim = reinterpret_cast<int32_t*>(p);
+}
+void carve(SurfQ& s, void* base, size_t cap) {
+    char* p = static_cast<char*>(base);
+    for (int k = 0; k < 3; k++) { s.p[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    for (int k = 0; k < 3; k++) { s.n[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    for (int k = 0; k < 3; k++) { s.wo[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    for (int k = 0; k < 3; k++) { s.albedo[k] = reinterpret_cast<double*>(p); p += cap * 8; }
+    s.pixel = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+    s.node = reinterpret_cast<int32_t*>(p); p += cap * 4;
+    s.material = reinterpret_cast<int32_t*>(p); p += cap * 4;
+    s.inside = reinterpret_cast<int32_t*>(p);
+}
+
+// Field-wise copy of n rays between two structure-of-arrays queues.
+hipError_t copy_rays(const RayQ& dst, uint64_t dst_at, const RayQ& src, uint64_t src_at, uint64_t n, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipMemcpyAsync(dst.o[k] + dst_at, src.o[k] + src_at, n * 8, hipMemcpyDeviceToDevice, s);
+    for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipMemcpyAsync(dst.d[k] + dst_at, src.d[k] + src_at, n * 8, hipMemcpyDeviceToDevice, s);
+    for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipMemcpyAsync(dst.rad[k] + dst_at, src.rad[k] + src_at, n * 8, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst.pixel + dst_at, src.pixel + src_at, n * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst.sample + dst_at, src.sample + src_at, n * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst.path + dst_at, src.path + src_at, n * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst.depth_n + dst_at, src.depth_n + src_at, n * 4, hipMemcpyDeviceToDevice, s);
+    return e;
+}
+
+int ensure_work(rt_scene* sc) {
+    if (sc->work) return RT_OK;
+    auto* w = new WorkBuffers();
+    sc->work = w;
+    w->q = (uint32_t)env_size("RT_QUEUE_RAYS", (size_t)1 << 23);
+    if (w->q < 64 * 64) w->q = 64 * 64;
+    const size_t q = w->q;
+    char *rays = nullptr, *sray = nullptr, *shit = nullptr, *surfs = nullptr;
+    // a scene that never shades needs none of the queues (kernels still get valid pointers)
+    const size_t qq = sc->all_terminal ? 64 : q;
+    HIP_TRY(w->mem.alloc(2 * qq * kRayBytes, &rays));
+    HIP_TRY(w->mem.alloc(qq * kRayBytes, &sray));
+    HIP_TRY(w->mem.alloc(qq * kHitBytes, &shit));
+    HIP_TRY(w->mem.alloc(qq * kSurfBytes, &surfs));
+    HIP_TRY(w->mem.alloc(1, &w->queues.counters));
+    carve(w->queues.rays, rays, 2 * qq);
+    carve(w->queues.shade_ray, sray, qq);
+    carve(w->queues.shade_hit, shit, qq);
+    carve(w->queues.surfs, surfs, qq);
+    w->queues.ray_capacity = (uint32_t)(2 * qq);
+    w->queues.shade_capacity = (uint32_t)qq;
+    w->queues.surf_capacity = (uint32_t)qq;
+    return RT_OK;
+}
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+struct EventPool {  // HIP-event timing of the traversal launches, on the stream they run on
+    std::vector<EventPair> events;
+    size_t used = 0;
+    double ms = 0;
+    ~EventPool() {
+        for (auto& ev : events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    }
+    hipError_t next(EventPair** out) {
+        if (used == events.size()) {
+            EventPair ev;
+            hipError_t e = hipEventCreate(&ev.a);
+            if (e == hipSuccess) e = hipEventCreate(&ev.b);
+            if (e != hipSuccess) return e;
+            events.push_back(ev);
+        }
+        *out = &events[used++];
+        return hipSuccess;
+    }
+    hipError_t drain() {  // call only after the stream has been synchronised
+        for (size_t i = 0; i < used; i++) {
+            float t = 0;
+            hipError_t e = hipEventElapsedTime(&t, events[i].a, events[i].b);
+            if (e != hipSuccess) return e;
+            ms += t;
+        }
+        used = 0;
+        return hipSuccess;
+    }
+};
+
+}  // namespace
+
+int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba) {
+    if (int rc = ensure_work(sc)) return rc;
+    WorkBuffers& w = *sc->work;
+    const size_t px = (size_t)dx * dy;
+    if (w.rgba_bytes < px * 4) {
+        if (w.rgba) (void)hipFree(w.rgba);
+        w.rgba = nullptr;
+        w.rgba_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.rgba), px * 4));
+        w.rgba_bytes = px * 4;
+    }
+    if (w.film_doubles < px * 3) {
+        if (w.film) (void)hipFree(w.film);
+        w.film = nullptr;
+        w.film_doubles = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.film), px * 3 * sizeof(double)));
+        w.film_doubles = px * 3;
+    }
+    *film = w.film;
+    *rgba = w.rgba;
+    return RT_OK;
+}
+
+int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats) {
+    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    if (!sc || !camera || !o || !film) return fail(RT_ERR_INVALID, "null argument");
+    // RenderOptions.Validate, render.go:81-98
+    if (o->seed < 0) return fail(RT_ERR_INVALID, "bad Seed must be non-negative but got " + std::to_string(o->seed));
+    if (o->rays_per_pixel <= 0) return fail(RT_ERR_INVALID, "bad RaysPerPixel must be positive but got " + std::to_string(o->rays_per_pixel));
+    if (o->max_ray_depth <= 0) return fail(RT_ERR_INVALID, "bad MaxRayDepth must be positive but got " + std::to_string(o->max_ray_depth));
+    if (o->dx <= 0) return fail(RT_ERR_INVALID, "bad Dx must be positive but got " + std::to_string(o->dx));
+    if (o->dy <= 0) return fail(RT_ERR_INVALID, "bad Dy must be positive but got " + std::to_string(o->dy));
+    if (o->max_ray_depth > 30) return fail(RT_ERR_UNSUPPORTED, "MaxRayDepth above 30 is not supported (path-tree index is 32 bit)");
+    if ((uint64_t)o->dx * (uint64_t)o->dy >= 0xFFFFFFFFull) return fail(RT_ERR_UNSUPPORTED, "image too large");
+    if (o->mode != RT_MODE_REFERENCE && o->mode != RT_MODE_FAST) return fail(RT_ERR_INVALID, "unknown mode");
+    const int world = o->band_world > 0 ? o->band_world : 1;
+    const int rank = o->band_rank;
+    if (rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "band_rank out of range");
+    if (o->sample_count < 0 || o->sample_begin < 0 || (o->sample_count > 0 && o->sample_begin + o->sample_count > o->rays_per_pixel))
+        return fail(RT_ERR_INVALID, "sample range outside [0, RaysPerPixel)");
+    HIP_TRY(hipSetDevice(sc->device));
+    DCamera cam;
+    if (int rc = make_camera(*camera, cam)) return rc;
+    if (int rc = ensure_work(sc)) return rc;
+    WorkBuffers& w = *sc->work;
+    Queues& q = w.queues;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(o->stream);
+    sc->cancel.store(false);
+
+    const auto t_start = std::chrono::steady_clock::now();
+    int local_rows = 0;
+    for (int r = 0; r < o->dy; r++)
+        if ((r / 16) % world == rank) local_rows++;
+    PassDesc pass{};
+    pass.dx = o->dx;
+    pass.dy = o->dy;
+    pass.band_rank = rank;
+    pass.band_world = world;
+    pass.local_rows = local_rows;
+    pass.tiles_x = (o->dx + 7) / 8;
+    pass.spp = o->rays_per_pixel;
+    pass.seed_lo = (uint32_t)((uint64_t)o->seed & 0xffffffffu);
+    pass.seed_hi = (uint32_t)((uint64_t)o->seed >> 32);
+    pass.max_depth = o->max_ray_depth;
+    const int64_t tiles_total = (int64_t)pass.tiles_x * ((local_rows + 7) / 8);
+    const int s_first = o->sample_count > 0 ? o->sample_begin : 0;
+    const int s_end = o->sample_count > 0 ? o->sample_begin + o->sample_count : o->rays_per_pixel;
+    // paths per primary launch: bounded by the shade queue unless nothing is ever queued
+    const int64_t paths_per_launch = sc->all_terminal ? ((int64_t)1 << 40) : (int64_t)w.q;
+
+    HIP_TRY(hipMemsetAsync(q.counters, 0, sizeof(Counters), stream));
+    EventPool events;
+    uint64_t traverse_launches = 0, traverse_rays = 0;
+    Counters host{};
+    uint64_t pool_top = 0;
+
+    auto read_counters = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(&host, q.counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(events.drain());
+        return RT_OK;
+    };
+    auto reset_cursors = [&]() -> int {  // zero the three append cursors, keep the statistics
+        HIP_TRY(hipMemsetAsync(&q.counters->shade_count, 0, 3 * sizeof(unsigned int), stream));
+        return RT_OK;
+    };
+
+    for (int s0 = s_first; s0 < s_end;) {
+        // a pass covers all tiles for a run of samples when that fits, else a run of tiles for one sample
+        int s_count = 1;
+        if (tiles_total * 64 <= paths_per_launch)
+            s_count = (int)std::min<int64_t>(std::min(s_end - s0, 64), paths_per_launch / std::max<int64_t>(tiles_total * 64, 1));
+        const int64_t tiles_per_launch = std::max<int64_t>(1, paths_per_launch / (64 * (int64_t)s_count));
+        for (int64_t t0 = 0; t0 < tiles_total; t0 += tiles_per_launch) {
+            if (sc->cancel.load()) {
+                (void)hipStreamSynchronize(stream);
+                return fail(RT_ERR_CANCELLED, "render cancelled");
+            }
+            const int64_t nt = std::min(tiles_per_launch, tiles_total - t0);
+            pass.sample_begin = s0;
+            pass.sample_count = s_count;
+            pass.tile_begin = t0;
+            pass.n_pixels = nt * 64;
+            if (int rc = reset_cursors()) return rc;
+            EventPair* ev = nullptr;
+            HIP_TRY(events.next(&ev));
+            HIP_TRY(hipEventRecord(ev->a, stream));
+            launch_primary(sc->dev, cam, pass, q, o->mode, sc->mesh_only, film, stream);
+            HIP_TRY(hipEventRecord(ev->b, stream));
+            HIP_TRY(hipGetLastError());
+            traverse_launches++;
+            traverse_rays += (uint64_t)pass.n_pixels * (uint64_t)s_count;
+            if (sc->all_terminal) {
+                if (events.used >= 256) {  // bound the number of live events without stalling every pass
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    HIP_TRY(events.drain());
+                }
+                continue;
+            }
+            // generations of scattered rays
+            uint32_t n_traced = (uint32_t)std::min<int64_t>(pass.n_pixels * s_count, q.shade_capacity);
+            for (;;) {
+                if (sc->cancel.load()) {
+                    (void)hipStreamSynchronize(stream);
+                    return fail(RT_ERR_CANCELLED, "render cancelled");
+                }
+                launch_shade(sc->dev, pass, q, n_traced, film, stream);  // grid = upper bound; the kernel reads the real count
+                HIP_TRY(hipGetLastError());
+                if (int rc = read_counters()) return rc;
+                if (host.shade_count > q.shade_capacity || host.next_count > q.ray_capacity || host.surf_count > q.surf_capacity)
+                    return fail(RT_ERR_DEVICE, "internal queue overflow");
+                if (host.surf_count > 0) {
+                    launch_direct(sc->dev, q, host.surf_count, o->mode, film, stream);
+                    HIP_TRY(hipGetLastError());
+                }
+                uint32_t n = host.next_count;
+                if (n > w.q) {  // park the excess on the overflow stack; bounded by q * (MaxRayDepth + 1)
+                    const uint64_t excess = n - w.q;
+                    if (!w.pool_base) {
+                        const uint64_t want = (uint64_t)w.q * (uint64_t)(o->max_ray_depth + 1);
+                        hipError_t pe = hipMalloc(&w.pool_base, want * kRayBytes);
+                        if (pe != hipSuccess) { w.pool_base = nullptr; return fail(RT_ERR_NOMEM, hipGetErrorString(pe)); }
+                        carve(w.pool, w.pool_base, want);
+                        w.pool_capacity = want;
+                    }
+                    if (pool_top + excess > w.pool_capacity) return fail(RT_ERR_NOMEM, "ray pool exhausted");
+                    HIP_TRY(copy_rays(w.pool, pool_top, q.rays, w.q, excess, stream));
+                    pool_top += excess;
+                    n = w.q;
+                }
+                if (n == 0) {
+                    if (pool_top == 0) break;
+                    const uint64_t take = std::min<uint64_t>(pool_top, w.q);
+                    HIP_TRY(copy_rays(q.rays, 0, w.pool, pool_top - take, take, stream));
+                    pool_top -= take;
+                    n = (uint32_t)take;
+                }
+                if (int rc = reset_cursors()) return rc;
+                HIP_TRY(events.next(&ev));
+                HIP_TRY(hipEventRecord(ev->a, stream));
+                launch_trace(sc->dev, q, n, o->mode, sc->mesh_only, film, stream);
+                HIP_TRY(hipEventRecord(ev->b, stream));
+                HIP_TRY(hipGetLastError());
+                traverse_launches++;
+                traverse_rays += n;
+                n_traced = n;
+            }
+        }
+        s0 += s_count;
+    }
+    if (int rc = read_counters()) return rc;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->total_rays = host.total;
+        stats->rays_exceeded_depth = host.exceeded;
+        stats->rays_left_scene = host.left;
+        stats->shadow_rays = host.shadow;
+        stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        stats->traverse_seconds = events.ms * 1e-3;
+        stats->traverse_launches = traverse_launches;
+        stats->traverse_rays = traverse_rays;
+    }
+    return RT_OK;
+}
+
+}  // namespace rt

@@ -14,12 +14,9 @@
 
 #include "bvh_build.h"
 #include "dev_math.h"
-#include "kernels.h"
-#include "scene_types.h"
+#include "host_common.h"
 
-namespace {
-
-using namespace rt;
+namespace rt {
 
 thread_local std::string tl_error;
 std::atomic<bool> g_initialized{false};
@@ -30,65 +27,11 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                         \
-    do {                                                                                                      \
-        hipError_t e_ = (expr);                                                                               \
-        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-struct DeviceBuffers {
-    std::vector<void*> ptrs;
-    ~DeviceBuffers() {
-        for (void* p : ptrs) (void)hipFree(p);
-    }
-    template <typename T>
-    hipError_t upload(const std::vector<T>& host, const T** out) {
-        T* d = nullptr;
-        size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(T);
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), bytes);
-        if (e != hipSuccess) return e;
-        ptrs.push_back(d);
-        if (!host.empty()) e = hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
-        *out = d;
-        return e;
-    }
-    template <typename T>
-    hipError_t alloc(size_t count, T** out) {
-        T* d = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), std::max<size_t>(count, 1) * sizeof(T));
-        if (e == hipSuccess) ptrs.push_back(d);
-        *out = d;
-        return e;
-    }
-};
-
-struct WorkBuffers {  // queues of the wavefront loop, allocated at the first render
-    DeviceBuffers mem;
-    uint32_t q = 0;  // rays processed per launch at most
-    RayRec* rays[2] = {nullptr, nullptr};
-    HitRec* hits = nullptr;
-    SurfRec* surfs = nullptr;
-    Counters* counters = nullptr;
-    RayRec* pool = nullptr;  // overflow stack for generations that outgrow q
-    uint64_t pool_capacity = 0;
-    uint8_t* rgba = nullptr;
-    size_t rgba_bytes = 0;
-    double* film = nullptr;
-    size_t film_doubles = 0;
-};
-
-}  // namespace
-
-struct rt_scene {
-    DeviceBuffers mem;
-    DScene dev{};
-    std::vector<rt_bvh_info> bvh_info;
-    std::atomic<bool> cancel{false};
-    std::unique_ptr<WorkBuffers> work;
-    int device = 0;
-};
+}  // namespace rt
 
 namespace {
+
+using namespace rt;
 
 // ---- host-side precomputation, same float64 operations as the reference's per-call set-up ----
 
@@ -143,7 +86,9 @@ DXform invert(const DXform& t) {  // Transform.Inverse, transform.go:86-102
     return r;
 }
 
-int make_camera(const rt_camera_desc& c, DCamera& d) {
+}  // namespace
+
+int rt::make_camera(const rt_camera_desc& c, DCamera& d) {
     std::memset(&d, 0, sizeof(d));
     d.kind = c.kind;
     d.intr = c;
@@ -179,6 +124,8 @@ int make_camera(const rt_camera_desc& c, DCamera& d) {
     return RT_OK;
 }
 
+namespace {
+
 int check_shape_ref(const rt_scene_desc& d, int kind, int index, int depth) {
     const uint64_t counts[6] = {d.n_spheres, d.n_quads, d.n_cylinders, d.n_triangles, d.n_meshes, d.n_transformed};
     if (kind < 0 || kind > 5 || index < 0 || (uint64_t)index >= counts[kind]) return fail(RT_ERR_INVALID, "shape reference out of range");
@@ -189,225 +136,11 @@ int check_shape_ref(const rt_scene_desc& d, int kind, int index, int depth) {
     return RT_OK;
 }
 
-size_t env_size(const char* name, size_t fallback) {
-    const char* v = std::getenv(name);
-    if (!v || !*v) return fallback;
-    return (size_t)std::strtoull(v, nullptr, 10);
-}
-
-int ensure_work(rt_scene* sc, int max_depth, int dx, int dy) {
-    if (!sc->work) {
-        auto w = std::make_unique<WorkBuffers>();
-        w->q = (uint32_t)env_size("RT_QUEUE_RAYS", (size_t)1 << 23);
-        if (w->q < 64 * 64) w->q = 64 * 64;
-        HIP_TRY(w->mem.alloc((size_t)w->q * 2, &w->rays[0]));
-        HIP_TRY(w->mem.alloc((size_t)w->q * 2, &w->rays[1]));
-        HIP_TRY(w->mem.alloc((size_t)w->q, &w->hits));
-        HIP_TRY(w->mem.alloc((size_t)w->q, &w->surfs));
-        HIP_TRY(w->mem.alloc(1, &w->counters));
-        sc->work = std::move(w);
-    }
-    WorkBuffers& w = *sc->work;
-    (void)max_depth;
-    const size_t px = (size_t)dx * dy;
-    if (w.rgba_bytes < px * 4) {
-        if (w.rgba) (void)hipFree(w.rgba);
-        w.rgba = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.rgba), px * 4));
-        w.rgba_bytes = px * 4;
-    }
-    return RT_OK;
-}
-
-struct EventPair {
-    hipEvent_t a = nullptr, b = nullptr;
-};
-
-// The wavefront loop for one process's share of the image; adds radiance sums into film.
-int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats) {
-    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
-    if (!sc || !camera || !o || !film) return fail(RT_ERR_INVALID, "null argument");
-    // RenderOptions.Validate, render.go:81-98
-    if (o->seed < 0) return fail(RT_ERR_INVALID, "bad Seed must be non-negative but got " + std::to_string(o->seed));
-    if (o->rays_per_pixel <= 0) return fail(RT_ERR_INVALID, "bad RaysPerPixel must be positive but got " + std::to_string(o->rays_per_pixel));
-    if (o->max_ray_depth <= 0) return fail(RT_ERR_INVALID, "bad MaxRayDepth must be positive but got " + std::to_string(o->max_ray_depth));
-    if (o->dx <= 0) return fail(RT_ERR_INVALID, "bad Dx must be positive but got " + std::to_string(o->dx));
-    if (o->dy <= 0) return fail(RT_ERR_INVALID, "bad Dy must be positive but got " + std::to_string(o->dy));
-    if (o->max_ray_depth > 30) return fail(RT_ERR_UNSUPPORTED, "MaxRayDepth above 30 is not supported (path-tree index is 32 bit)");
-    if ((uint64_t)o->dx * (uint64_t)o->dy >= 0xFFFFFFFFull) return fail(RT_ERR_UNSUPPORTED, "image too large");
-    if (o->mode != RT_MODE_REFERENCE && o->mode != RT_MODE_FAST) return fail(RT_ERR_INVALID, "unknown mode");
-    const int world = o->band_world > 0 ? o->band_world : 1;
-    const int rank = o->band_rank;
-    if (rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "band_rank out of range");
-    if (o->sample_count < 0 || o->sample_begin < 0 || (o->sample_count > 0 && o->sample_begin + o->sample_count > o->rays_per_pixel))
-        return fail(RT_ERR_INVALID, "sample range outside [0, RaysPerPixel)");
-    HIP_TRY(hipSetDevice(sc->device));
-    DCamera cam;
-    if (int rc = make_camera(*camera, cam)) return rc;
-    if (int rc = ensure_work(sc, o->max_ray_depth, o->dx, o->dy)) return rc;
-    WorkBuffers& w = *sc->work;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(o->stream);
-    sc->cancel.store(false);
-
-    const auto t_start = std::chrono::steady_clock::now();
-    int local_rows = 0;
-    for (int r = 0; r < o->dy; r++)
-        if ((r / 16) % world == rank) local_rows++;
-    PassDesc pass{};
-    pass.dx = o->dx;
-    pass.dy = o->dy;
-    pass.band_rank = rank;
-    pass.band_world = world;
-    pass.local_rows = local_rows;
-    pass.tiles_x = (o->dx + 7) / 8;
-    pass.spp = o->rays_per_pixel;
-    pass.seed_lo = (uint32_t)((uint64_t)o->seed & 0xffffffffu);
-    pass.seed_hi = (uint32_t)((uint64_t)o->seed >> 32);
-    pass.max_depth = o->max_ray_depth;
-    const int64_t tiles_total = (int64_t)pass.tiles_x * ((local_rows + 7) / 8);
-    const int64_t tiles_per_launch = std::max<int64_t>(1, w.q / 64);
-
-    HIP_TRY(hipMemsetAsync(w.counters, 0, sizeof(Counters), stream));
-    Queues q{};
-    q.hits = w.hits;
-    q.surfs = w.surfs;
-    q.counters = w.counters;
-    q.next_capacity = w.q * 2;
-    q.surf_capacity = w.q;
-
-    std::vector<EventPair> events;
-    size_t events_used = 0;
-    double traverse_ms = 0;
-    uint64_t traverse_launches = 0, traverse_rays = 0;
-    auto drain_events = [&]() -> hipError_t {
-        for (size_t i = 0; i < events_used; i++) {
-            float ms = 0;
-            hipError_t e = hipEventElapsedTime(&ms, events[i].a, events[i].b);
-            if (e != hipSuccess) return e;
-            traverse_ms += ms;
-        }
-        events_used = 0;
-        return hipSuccess;
-    };
-    auto cleanup_events = [&]() {
-        for (auto& ev : events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    };
-    Counters host_counters{};
-    uint64_t pool_top = 0;
-    int rc = RT_OK;
-
-    // one generation: extend, shade (+ light loop); returns the number of children in rays[1 - cur]
-    auto run_generation = [&](int cur, uint32_t n, uint32_t& n_next) -> int {
-        // zero the two append counters, keep the statistics
-        HIP_TRY(hipMemsetAsync(&w.counters->next_count, 0, 2 * sizeof(unsigned int), stream));
-        if (events_used == events.size()) {
-            EventPair ev;
-            HIP_TRY(hipEventCreate(&ev.a));
-            HIP_TRY(hipEventCreate(&ev.b));
-            events.push_back(ev);
-        }
-        EventPair& ev = events[events_used++];
-        HIP_TRY(hipEventRecord(ev.a, stream));
-        launch_extend(sc->dev, w.rays[cur], w.hits, n, o->mode, stream);
-        HIP_TRY(hipEventRecord(ev.b, stream));
-        traverse_launches++;
-        traverse_rays += n;
-        q.rays = w.rays[cur];
-        q.next = w.rays[1 - cur];
-        launch_shade(sc->dev, pass, q, n, film, stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&host_counters, w.counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(drain_events());
-        if (host_counters.surf_count > q.surf_capacity || host_counters.next_count > q.next_capacity)
-            return fail(RT_ERR_DEVICE, "internal queue overflow");
-        if (host_counters.surf_count > 0) {
-            launch_direct(sc->dev, q, host_counters.surf_count, o->mode, film, stream);
-            HIP_TRY(hipGetLastError());
-        }
-        n_next = host_counters.next_count;
-        return RT_OK;
-    };
-
-    const int s_first = o->sample_count > 0 ? o->sample_begin : 0;
-    const int s_end = o->sample_count > 0 ? o->sample_begin + o->sample_count : o->rays_per_pixel;
-    for (int s0 = s_first; s0 < s_end && rc == RT_OK;) {
-        // a pass covers either all tiles for a run of samples, or a run of tiles for one sample
-        int s_count = 1;
-        if (tiles_total <= tiles_per_launch) s_count = (int)std::min<int64_t>(s_end - s0, tiles_per_launch / std::max<int64_t>(tiles_total, 1));
-        for (int64_t t0 = 0; t0 < tiles_total && rc == RT_OK; t0 += tiles_per_launch) {
-            const int64_t nt = std::min(tiles_per_launch, tiles_total - t0);
-            pass.sample_begin = s0;
-            pass.sample_count = s_count;
-            pass.tile_begin = t0;
-            pass.n_paths = nt * 64 * s_count;
-            int cur = 0;
-            launch_generate(cam, pass, w.rays[cur], stream);
-            uint32_t n = (uint32_t)pass.n_paths;
-            while (rc == RT_OK) {
-                if (sc->cancel.load()) { rc = fail(RT_ERR_CANCELLED, "render cancelled"); break; }
-                uint32_t n_next = 0;
-                if (n > 0) {
-                    rc = run_generation(cur, n, n_next);
-                    if (rc != RT_OK) break;
-                    cur = 1 - cur;
-                }
-                if (n_next > w.q) {  // park the excess on the overflow stack
-                    const uint64_t excess = n_next - w.q;
-                    if (!w.pool) {  // a generation can outgrow q only through Dielectric's two children; bounded by depth
-                        const uint64_t want = (uint64_t)w.q * (uint64_t)(o->max_ray_depth + 1);
-                        hipError_t pe = hipMalloc(reinterpret_cast<void**>(&w.pool), want * sizeof(RayRec));
-                        if (pe != hipSuccess) { w.pool = nullptr; rc = fail(RT_ERR_NOMEM, hipGetErrorString(pe)); break; }
-                        w.pool_capacity = want;
-                    }
-                    if (pool_top + excess > w.pool_capacity) { rc = fail(RT_ERR_NOMEM, "ray pool exhausted"); break; }
-                    hipError_t e = hipMemcpyAsync(w.pool + pool_top, w.rays[cur] + w.q, excess * sizeof(RayRec), hipMemcpyDeviceToDevice, stream);
-                    if (e != hipSuccess) { rc = fail(RT_ERR_DEVICE, hipGetErrorString(e)); break; }
-                    pool_top += excess;
-                    n_next = w.q;
-                }
-                n = n_next;
-                if (n == 0) {
-                    if (pool_top == 0) break;
-                    const uint64_t take = std::min<uint64_t>(pool_top, w.q);
-                    hipError_t e = hipMemcpyAsync(w.rays[cur], w.pool + (pool_top - take), take * sizeof(RayRec), hipMemcpyDeviceToDevice, stream);
-                    if (e != hipSuccess) { rc = fail(RT_ERR_DEVICE, hipGetErrorString(e)); break; }
-                    pool_top -= take;
-                    n = (uint32_t)take;
-                }
-            }
-        }
-        s0 += s_count;
-    }
-    if (rc == RT_OK) {
-        hipError_t e = hipMemcpyAsync(&host_counters, w.counters, sizeof(Counters), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e == hipSuccess) e = drain_events();
-        if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, hipGetErrorString(e));
-    } else {
-        (void)hipStreamSynchronize(stream);
-    }
-    cleanup_events();
-    if (rc != RT_OK) return rc;
-    if (stats) {
-        std::memset(stats, 0, sizeof(*stats));
-        stats->total_rays = host_counters.total;
-        stats->rays_exceeded_depth = host_counters.exceeded;
-        stats->rays_left_scene = host_counters.left;
-        stats->shadow_rays = host_counters.shadow;
-        stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-        stats->traverse_seconds = traverse_ms * 1e-3;
-        stats->traverse_launches = traverse_launches;
-        stats->traverse_rays = traverse_rays;
-    }
-    return RT_OK;
-}
-
 }  // namespace
 
 extern "C" {
 
-const char* rt_last_error(void) { return tl_error.c_str(); }
+const char* rt_last_error(void) { return rt::tl_error.c_str(); }
 
 int rt_init(const int* gpu_ids, int n) {
     int count = 0;
@@ -481,7 +214,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             return fail(RT_ERR_INVALID, "invalid PointLight RadiantIntensity (should be non-negative)");
     if (d->n_nodes > 0x7fffffffull || d->n_lights > 65535) return fail(RT_ERR_UNSUPPORTED, "too many nodes or lights");
 
-    auto sc = std::make_unique<rt_scene>();
+    std::unique_ptr<rt_scene> sc(new rt_scene());
     sc->device = g_device;
     std::vector<DNode> nodes(d->n_nodes);
     for (uint64_t i = 0; i < d->n_nodes; i++) nodes[i] = {d->nodes[i].shape_kind, d->nodes[i].shape_index, d->nodes[i].material, 0};
@@ -571,6 +304,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HIP_TRY(sc->mem.upload(textures, &dev.textures));
     HIP_TRY(sc->mem.upload(images, &dev.images));
     HIP_TRY(sc->mem.upload(lights, &dev.lights));
+    sc->all_terminal = true;
+    for (const rt_material& m : materials)
+        if (m.kind != RT_MAT_EMITTER && m.kind != RT_MAT_DEBUG_UV && m.kind != RT_MAT_DEBUG_NORMAL) sc->all_terminal = false;
+    sc->mesh_only = d->n_nodes > 0;
+    for (const DNode& n : nodes)
+        if (n.kind != RT_SHAPE_MESH) sc->mesh_only = false;
     dev.n_nodes = (int32_t)d->n_nodes;
     dev.n_lights = (int32_t)d->n_lights;
     *out = sc.release();
@@ -580,11 +319,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 void rt_scene_destroy(rt_scene* scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
-    if (scene->work) {
-        if (scene->work->pool) (void)hipFree(scene->work->pool);
-        if (scene->work->rgba) (void)hipFree(scene->work->rgba);
-        if (scene->work->film) (void)hipFree(scene->work->film);
-    }
+    destroy_work(scene->work);
     delete scene;
 }
 
@@ -620,22 +355,17 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opt
     if (!scene || !opts || !rgba_out) return fail(RT_ERR_INVALID, "null argument");
     if (opts->dx <= 0 || opts->dy <= 0) return fail(RT_ERR_INVALID, "bad Dx / Dy must be positive");
     if (stride < (size_t)opts->dx * 4) return fail(RT_ERR_INVALID, "stride smaller than a row");
-    if (int rc = ensure_work(scene, std::max(opts->max_ray_depth, 1), opts->dx, opts->dy)) return rc;
-    WorkBuffers& w = *scene->work;
+    HIP_TRY(hipSetDevice(scene->device));
+    double* film = nullptr;
+    uint8_t* rgba = nullptr;
+    if (int rc = scene_film(scene, opts->dx, opts->dy, &film, &rgba)) return rc;
     const size_t n = (size_t)opts->dx * opts->dy * 3;
-    if (w.film_doubles < n) {
-        if (w.film) (void)hipFree(w.film);
-        w.film = nullptr;
-        w.film_doubles = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.film), n * sizeof(double)));
-        w.film_doubles = n;
-    }
     hipStream_t stream = reinterpret_cast<hipStream_t>(opts->stream);
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipMemsetAsync(w.film, 0, n * sizeof(double), stream));
-    if (int rc = render_into_film(scene, camera, opts, w.film, stats)) return rc;
-    launch_resolve(w.film, opts->dx, opts->dy, opts->rays_per_pixel, w.rgba, stream);
-    HIP_TRY(hipMemcpy2DAsync(rgba_out, stride, w.rgba, (size_t)opts->dx * 4, (size_t)opts->dx * 4, (size_t)opts->dy, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemsetAsync(film, 0, n * sizeof(double), stream));
+    if (int rc = render_into_film(scene, camera, opts, film, stats)) return rc;
+    launch_resolve(film, opts->dx, opts->dy, opts->rays_per_pixel, rgba, stream);
+    HIP_TRY(hipMemcpy2DAsync(rgba_out, stride, rgba, (size_t)opts->dx * 4, (size_t)opts->dx * 4, (size_t)opts->dy, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (stats) stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;

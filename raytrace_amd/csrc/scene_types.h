@@ -100,41 +100,49 @@ struct DCamera {
     rt_camera_desc intr;  // calibrated intrinsics are read from here
 };
 
-// One path segment waiting to be traced (render.go:22-30).
-struct RayRec {
-    double o[3];
-    double d[3];
-    double rad[3];     // ray.radiance
-    uint32_t pixel;    // film index: image row * dx + x (row 0 = top)
-    uint32_t sample;
-    uint32_t path;     // position in the path tree (root 1, children 2p, 2p+1)
-    uint32_t depth_n;  // depth << 24 | random draws made on this ray's stream
-};
+// Queues are structure-of-arrays: lane i of a wave reads element i of every field, so each
+// load or store instruction of a wave covers one contiguous run of memory.
 
-struct HitRec {  // shape.go:11-16 plus which node / face
-    int32_t node, prim;
-    double t;
-    double at[3];
-    double normal[3];
-    double uv[2];
+// Path segments waiting to be traced (render.go:22-30).
+struct RayQ {
+    double* o[3];
+    double* d[3];
+    double* rad[3];     // ray.radiance
+    uint32_t* pixel;    // film index: image row * dx + x (row 0 = top)
+    uint32_t* sample;
+    uint32_t* path;     // position in the path tree (root 1, children 2p, 2p+1)
+    uint32_t* depth_n;  // depth << 24 | random draws made so far on this ray's stream
 };
+constexpr size_t kRayBytes = 9 * 8 + 4 * 4;
 
-// A lit surface point waiting for its light loop (material_*.go ComputeDirectLighting).
-struct SurfRec {
-    double p[3];
-    double n[3];       // normal used for the offset and the cosine (flipped inside a dielectric)
-    double wo[3];      // unit direction back along the incoming ray
-    double albedo[3];  // Lambertian texture value / Metal albedo
-    uint32_t pixel;
-    int32_t node;
-    int32_t material;
-    int32_t inside;    // dielectric: the hit was from inside
+// Collisions (shape.go:11-16) plus which node / face, same index as the ray they belong to.
+struct HitQ {
+    int32_t* node;
+    int32_t* prim;
+    double* t;
+    double* at[3];
+    double* nrm[3];
+    double* uv[2];
 };
+constexpr size_t kHitBytes = 2 * 4 + 9 * 8;
+
+// Lit surface points waiting for their light loop (material_*.go ComputeDirectLighting).
+struct SurfQ {
+    double* p[3];
+    double* n[3];       // normal used for the offset and the cosine (flipped inside a dielectric)
+    double* wo[3];      // unit direction back along the incoming ray
+    double* albedo[3];  // Lambertian texture value / Metal albedo
+    uint32_t* pixel;
+    int32_t* node;
+    int32_t* material;
+    int32_t* inside;    // dielectric: the hit was from inside
+};
+constexpr size_t kSurfBytes = 12 * 8 + 4 * 4;
 
 struct Counters {
-    unsigned long long total, exceeded, left, shadow;
-    unsigned int next_count, surf_count;
-    unsigned int pad[2];
+    unsigned long long total, exceeded, left, shadow;  // RenderStats (render.go:38-45) + occlusion rays
+    unsigned int shade_count, next_count, surf_count;  // append cursors of the three queues
+    unsigned int pad;
 };
 
 }  // namespace rt
