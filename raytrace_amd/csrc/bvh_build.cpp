@@ -194,24 +194,64 @@ struct Flattener {
         ref(n->right.get());
     }
 
-    void set_child(FastNode& f, int k, const TreeNode* c) {
+    const Box* face_box = nullptr;   // Face.Bounds() per face
+    const uint32_t* order = nullptr; // leaf order -> face
+
+    void set_box(FastNode& f, int k, const Box& b) {
         for (int a = 0; a < 3; a++) {
-            f.lo[k][a] = round_down(c->box.mn[a] - out.center[a]) - out.pad;
-            f.hi[k][a] = round_up(c->box.mx[a] - out.center[a]) + out.pad;
+            f.lo[k][a] = round_down(b.mn[a] - out.center[a]) - out.pad;
+            f.hi[k][a] = round_up(b.mx[a] - out.center[a]) + out.pad;
         }
+    }
+    Box range_box(uint32_t first, uint32_t count) const {
+        Box b = face_box[order[first]];
+        for (uint32_t i = 1; i < count; i++) b = unite(b, face_box[order[first + i]]);
+        return b;
+    }
+    static int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+    // A run of prims that is too long for one leaf reference: halve it under extra nodes.
+    int32_t fast_depth = 0, cur_depth = 0;
+    struct DepthScope {
+        Flattener& f;
+        explicit DepthScope(Flattener& fl) : f(fl) { f.cur_depth++; f.fast_depth = std::max(f.fast_depth, f.cur_depth); }
+        ~DepthScope() { f.cur_depth--; }
+    };
+
+    int32_t chunk(uint32_t first, uint32_t count) {
+        if (count <= 8) return leaf_ref(first, count);
+        DepthScope scope(*this);
+        const int32_t me = (int32_t)out.fast_nodes.size();
+        out.fast_nodes.emplace_back();
+        const uint32_t half = count / 2;
+        const uint32_t f0[2] = {first, first + half}, c0[2] = {half, count - half};
+        for (int k = 0; k < 2; k++) {
+            const Box b = range_box(f0[k], c0[k]);
+            const int32_t ref = never_hit(b) ? kFastEmpty : chunk(f0[k], c0[k]);
+            FastNode f = out.fast_nodes[me];
+            set_box(f, k, b);
+            f.child[k] = ref;
+            out.fast_nodes[me] = f;
+        }
+        return me;
+    }
+
+    int32_t child_ref(const TreeNode* c) {
+        if (never_hit(c->box)) return kFastEmpty;
+        if (!c->left) return chunk(c->first, c->count);
+        return fast(c);
     }
 
     int32_t fast(const TreeNode* n) {  // n is an inner node
+        DepthScope scope(*this);
         const int32_t me = (int32_t)out.fast_nodes.size();
         out.fast_nodes.emplace_back();
         const TreeNode* kids[2] = {n->left.get(), n->right.get()};
         for (int k = 0; k < 2; k++) {
-            const TreeNode* c = kids[k];
+            const int32_t ref = child_ref(kids[k]);  // may grow (reallocate) fast_nodes
             FastNode f = out.fast_nodes[me];
-            set_child(f, k, c);
-            if (never_hit(c->box)) { f.child[k] = 0; f.count[k] = -1; }
-            else if (!c->left) { f.child[k] = (int32_t)c->first; f.count[k] = (int32_t)c->count; }
-            else { f.count[k] = 0; out.fast_nodes[me] = f; int32_t ci = fast(c); f = out.fast_nodes[me]; f.child[k] = ci; }
+            set_box(f, k, kids[k]->box);
+            f.child[k] = ref;
             out.fast_nodes[me] = f;
         }
         return me;
@@ -250,26 +290,45 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
         radius = std::max(radius, std::max(std::fabs(root->box.mn[k] - out.center[k]), std::fabs(root->box.mx[k] - out.center[k])));
     }
     out.pad = round_up(radius * kBoxPad);
+    out.radius = (float)radius;
+    fl.face_box = boxes.data();
+    fl.order = b.order.data();
+    out.fast_nodes.reserve(n_faces + 1);
     if (root->left) {
-        out.fast_nodes.reserve(n_faces / 2 + 1);
         fl.fast(root.get());
     } else {  // the whole mesh is one leaf: give it a parent so traversal has a node to start from
-        FastNode f{};
-        fl.set_child(f, 0, root.get());
-        if (never_hit(root->box)) { f.child[0] = 0; f.count[0] = -1; }
-        else { f.child[0] = (int32_t)root->first; f.count[0] = (int32_t)root->count; }
-        f.child[1] = 0; f.count[1] = -1;
+        out.fast_nodes.emplace_back();
+        const int32_t ref = fl.child_ref(root.get());
+        FastNode f = out.fast_nodes[0];
+        fl.set_box(f, 0, root->box);
+        f.child[0] = ref;
+        f.child[1] = kFastEmpty;
         for (int a = 0; a < 3; a++) { f.lo[1][a] = 1.0f; f.hi[1][a] = -1.0f; }
-        out.fast_nodes.push_back(f);
+        out.fast_nodes[0] = f;
     }
 
+    out.fast_depth = std::max(fl.fast_depth, 1);
     out.prim_face.resize(n_faces);
     out.prim_pos.resize(n_faces * 9);
+    out.prim_tri32.resize(n_faces);
     for (uint64_t i = 0; i < n_faces; i++) {
         const uint32_t fi = b.order[i];
         out.prim_face[i] = (int32_t)fi;
         for (int v = 0; v < 3; v++)
             for (int k = 0; k < 3; k++) out.prim_pos[i * 9 + v * 3 + k] = faces[fi].v[v][k];
+        Tri32& t = out.prim_tri32[i];
+        double l1 = 0, l2 = 0;
+        for (int k = 0; k < 3; k++) {
+            const double e1 = faces[fi].v[1][k] - faces[fi].v[0][k], e2 = faces[fi].v[2][k] - faces[fi].v[0][k];
+            t.p0[k] = (float)(faces[fi].v[0][k] - out.center[k]);
+            t.e1[k] = (float)e1;
+            t.e2[k] = (float)e2;
+            l1 += e1 * e1;
+            l2 += e2 * e2;
+        }
+        t.len1 = round_up(std::sqrt(l1));
+        t.len2 = round_up(std::sqrt(l2));
+        t.pad = 0;
     }
     out.info.n_faces = n_faces;
     out.info.n_nodes = out.ref_nodes.size();

@@ -23,24 +23,41 @@ static_assert(sizeof(RefNode) == 64, "RefNode layout");
 // Node of the traversal-optimised tree: both children's boxes live in the parent so
 // one 64-byte fetch decides both descents.  Boxes are float32, relative to the
 // mesh's centre, rounded outward and padded (see kBoxPad in bvh_build.cpp).
-// child[k] >= 0 with count[k] == 0: inner node index; count[k] > 0: leaf with prims
-// [child[k], child[k] + count[k]); count[k] < 0: nothing there (skip).
+// child[k] >= 0: inner node index.  child[k] == kFastEmpty: nothing there.  Any other negative
+// value is a leaf: ~child[k] = first_prim << 3 | (count - 1), count <= 8 (larger leaves of the
+// reference tree are cut into runs of <= 8 prims under extra inner nodes).
+constexpr int32_t kFastEmpty = INT32_MIN;
 struct FastNode {
     float lo[2][3];
     float hi[2][3];
     int32_t child[2];
-    int32_t count[2];
+    int32_t pad[2];
 };
 static_assert(sizeof(FastNode) == 64, "FastNode layout");
+
+// Float32 copy of a face for the conservative pre-test that runs before the float64
+// intersection: p0 relative to the mesh centre, the two edges, and their lengths (the
+// error bound of the pre-test scales with them).  48 bytes.
+struct Tri32 {
+    float p0[3];
+    float e1[3];
+    float e2[3];
+    float len1, len2;
+    float pad;
+};
+static_assert(sizeof(Tri32) == 48, "Tri32 layout");
 
 struct MeshBvh {
     std::vector<RefNode> ref_nodes;
     std::vector<FastNode> fast_nodes;
     std::vector<int32_t> prim_face;   // leaf order -> face index inside the mesh
     std::vector<double> prim_pos;     // leaf order, 9 float64 per face (P0, P1, P2)
+    std::vector<Tri32> prim_tri32;    // leaf order
     double center[3];                 // origin of the float32 frame
     double root_box[6];
     float pad;                        // absolute padding applied to every float32 box
+    float radius;                     // largest |coordinate| of the mesh in its own frame
+    int32_t fast_depth;               // levels of inner nodes in the fast tree
     rt_bvh_info info;
 };
 

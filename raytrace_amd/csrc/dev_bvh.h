@@ -116,114 +116,141 @@ RT_DEV float up32(double x) {  // float32 not below x
     return f;
 }
 
-// Traversal stack of (node, entry distance) pairs.  The first kLdsPairs pairs live in LDS
-// (this lane's column: dword i at lds[i * stride]); deeper pairs spill to private memory.
-#ifndef RT_LDS_PAIRS
-#define RT_LDS_PAIRS 12
-#endif
-constexpr int kLdsPairs = RT_LDS_PAIRS;
-constexpr int kSpillPairs = 40 - RT_LDS_PAIRS;  // together >= the builder's depth limit of 32 plus the root
-
+// Traversal stack of (child reference, entry distance) pairs, entirely in LDS: this lane's
+// column of a [2 * pairs][lanes] array (dword i at lds[i * stride]).  Near-first descent pushes at
+// most one pair per tree level, so the host sizes the array from the depth of the deepest fast tree
+// of the scene and the stack cannot overflow; nothing goes to private (scratch) memory.
 struct PairStack {
     int32_t* lds;
     int stride;
+    int cap;  // pairs available
     int sp;
-    int32_t spill[2 * kSpillPairs];
-    RT_DEV void push(int32_t node, float t) {
-        if (sp < kLdsPairs) {
-            lds[(2 * sp) * stride] = node;
+    RT_DEV void push(int32_t ref, float t) {
+        if (sp < cap) {
+            lds[(2 * sp) * stride] = ref;
             lds[(2 * sp + 1) * stride] = __float_as_int(t);
-        } else if (sp - kLdsPairs < kSpillPairs) {
-            spill[2 * (sp - kLdsPairs)] = node;
-            spill[2 * (sp - kLdsPairs) + 1] = __float_as_int(t);
+            sp++;
         }
-        sp++;
     }
-    RT_DEV void pop(int32_t& node, float& t) {
+    RT_DEV void pop(int32_t& ref, float& t) {
         sp--;
-        if (sp < kLdsPairs) {
-            node = lds[(2 * sp) * stride];
-            t = __int_as_float(lds[(2 * sp + 1) * stride]);
-        } else {
-            node = spill[2 * (sp - kLdsPairs)];
-            t = __int_as_float(spill[2 * (sp - kLdsPairs) + 1]);
-        }
+        ref = lds[(2 * sp) * stride];
+        t = __int_as_float(lds[(2 * sp + 1) * stride]);
     }
 };
 
+// Conservative float32 pre-test of a face: true = the float64 test cannot accept this face.
+//
+// Moller-Trumbore without the division: with a = e1.(d x e2), U = s.(d x e2), V = d.(s x e1) the
+// float64 test accepts only if -e*a <= U, -e*a <= V and U + V <= (1 + e)*a for a > 0 (mirrored
+// for a < 0).  The float32 values differ from the exact ones by at most
+//   |dU| <= c * eps32 * |d| * |e2| * R,  |dV| <= c * eps32 * |d| * |e1| * R,  |da| <= c * eps32 * |d| * |e1| * |e2|
+// (R = mesh radius: inputs are rounded to float32 relative to the mesh centre, the shifted ray
+// origin lies within the padded root box, and every product is bounded by these magnitudes;
+// worst-case c is about 20, kErr carries 64).  A face is rejected only when a bound is violated
+// by more than these margins and the sign of a is certain.
+constexpr float kErr = 64.0f * 5.9604645e-8f;  // 64 * 2^-24
+
+RT_DEV bool tri32_rejects(const Tri32& t, const FastRay& f, float dx, float dy, float dz, float err_r /* kErr * |d| * R */,
+                          float err_d /* kErr * |d| */) {
+    const float hx = dy * t.e2[2] - dz * t.e2[1], hy = dz * t.e2[0] - dx * t.e2[2], hz = dx * t.e2[1] - dy * t.e2[0];
+    const float a = t.e1[0] * hx + t.e1[1] * hy + t.e1[2] * hz;
+    const float sx = f.ox - t.p0[0], sy = f.oy - t.p0[1], sz = f.oz - t.p0[2];
+    const float U = sx * hx + sy * hy + sz * hz;
+    const float qx = sy * t.e1[2] - sz * t.e1[1], qy = sz * t.e1[0] - sx * t.e1[2], qz = sx * t.e1[1] - sy * t.e1[0];
+    const float V = dx * qx + dy * qy + dz * qz;
+    const float eu = err_r * t.len2, ev = err_r * t.len1, ea = err_d * t.len1 * t.len2;
+    const float aa = fabsf(a);
+    if (!(aa > ea)) return false;  // sign of a uncertain (grazing or degenerate): let float64 decide
+    const float us = a < 0 ? -U : U, vs = a < 0 ? -V : V;
+    return us < -eu || vs < -ev || us + vs > aa + eu + ev + ea;
+}
+
+// Closest (or any) hit of one mesh.  while-while form: every lane first walks inner nodes until it
+// holds a leaf (or runs out of work), then the lanes of the wave test their leaves together, so the
+// float64 intersections run with most lanes active instead of stalling the node loop.
 template <bool ANY_HIT>
 RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, double tmin, double tmax, int& prim, double& t_out,
-                              double& u_out, double& v_out, int32_t* lds, int stride, VisitCounts& cnt) {
+                              double& u_out, double& v_out, int32_t* lds, int stride, int cap, VisitCounts& cnt) {
     FastRay f;
     if (!fast_setup(m, r, tmin, tmax, f)) return false;
     const FastNode* nodes = sc.fast_nodes + m.fast_off;
     const double* pos = sc.prim_pos + m.prim_off * 9;
+    const Tri32* tri32 = sc.prim_tri32 + m.prim_off;
     const float tmin32 = fmaxf(0.0f, (float)(tmin - f.t_shift));
     float tmax32 = up32(tmax - f.t_shift);
+    const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
+    const float dlen = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float err_d = kErr * dlen, err_r = err_d * m.radius;
     PairStack st;
     st.lds = lds;
     st.stride = stride;
+    st.cap = cap;
     st.sp = 0;
+    constexpr int32_t kDone = kFastEmpty;
     int32_t cur = 0;
     bool hit = false;
     for (;;) {
-        const FastNode n = nodes[cur];
-        cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
-        float tn[2];
-        bool go[2];
+        while (cur >= 0) {  // inner node: test both children, go to the nearer, push the farther
+            const FastNode n = nodes[cur];
+            cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
+            float tn[2];
+            bool go[2];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            float x0 = (n.lo[k][0] - f.ox) * f.ix, x1 = (n.hi[k][0] - f.ox) * f.ix;
-            float y0 = (n.lo[k][1] - f.oy) * f.iy, y1 = (n.hi[k][1] - f.oy) * f.iy;
-            float z0 = (n.lo[k][2] - f.oz) * f.iz, z1 = (n.hi[k][2] - f.oz) * f.iz;
-            // fminf / fmaxf return the other operand for a NaN (0 * inf on an in-plane axis): not constraining
-            float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin32));
-            float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax32));
-            tn[k] = tnear;
-            go[k] = (tnear <= tfar) && n.count[k] >= 0;
-        }
-        int32_t next = -1, other = -1;
-        float other_t = 0.0f;
-        const int first_k = (go[0] && go[1] && tn[1] < tn[0]) ? 1 : 0;  // nearer child first
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int k = j == 0 ? first_k : 1 - first_k;
-            if (!go[k]) continue;
-            if (n.count[k] > 0) {
-                if (tn[k] > tmax32) continue;  // the other leaf of this node already shrank the interval
-                const int32_t first = n.child[k];
-                for (int32_t q = 0; q < n.count[k]; q++) {
-                    const double* p = pos + (int64_t)(first + q) * 9;
-                    double t, u, v;
-                    cnt.prims++;
-                    if (mt_core(r, ld3(p), ld3(p + 3), ld3(p + 6), 1e-8, tmin, tmax, t, u, v)) {
-                        hit = true;
-                        if (ANY_HIT) return true;
-                        tmax = t;
-                        tmax32 = up32(t - f.t_shift);
-                        prim = first + q;
-                        t_out = t; u_out = u; v_out = v;
-                    }
-                }
-            } else if (next < 0) {
-                next = n.child[k];
+            for (int k = 0; k < 2; k++) {
+                const float x0 = (n.lo[k][0] - f.ox) * f.ix, x1 = (n.hi[k][0] - f.ox) * f.ix;
+                const float y0 = (n.lo[k][1] - f.oy) * f.iy, y1 = (n.hi[k][1] - f.oy) * f.iy;
+                const float z0 = (n.lo[k][2] - f.oz) * f.iz, z1 = (n.hi[k][2] - f.oz) * f.iz;
+                // fminf / fmaxf return the other operand for a NaN (0 * inf on an in-plane axis): not constraining
+                const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin32));
+                const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax32));
+                tn[k] = tnear;
+                go[k] = (tnear <= tfar) && n.child[k] != kFastEmpty;
+            }
+            if (go[0] && go[1]) {
+                const bool swap = tn[1] < tn[0];
+                st.push(swap ? n.child[0] : n.child[1], swap ? tn[0] : tn[1]);
+                cur = swap ? n.child[1] : n.child[0];
+            } else if (go[0] || go[1]) {
+                cur = go[0] ? n.child[0] : n.child[1];
             } else {
-                other = n.child[k];
-                other_t = tn[k];
+                cur = kDone;
+                while (st.sp > 0) {  // pop, skipping subtrees that begin beyond the current hit
+                    int32_t ref;
+                    float tnear;
+                    st.pop(ref, tnear);
+                    if (tnear <= tmax32) { cur = ref; break; }
+                }
             }
         }
-        if (next >= 0) {
-            if (other >= 0) st.push(other, other_t);
-            cur = next;
-            continue;
+        if (cur == kDone) break;
+        {  // leaf
+            const uint32_t code = (uint32_t)~cur;
+            const int32_t first = (int32_t)(code >> 3);
+            const int32_t count = (int32_t)(code & 7u) + 1;
+            for (int32_t q = 0; q < count; q++) {
+                cnt.prims++;
+                const Tri32 t32 = tri32[first + q];
+                if (tri32_rejects(t32, f, dx, dy, dz, err_r, err_d)) continue;
+                const double* p = pos + (int64_t)(first + q) * 9;
+                double t, u, v;
+                if (mt_core(r, ld3(p), ld3(p + 3), ld3(p + 6), 1e-8, tmin, tmax, t, u, v)) {
+                    hit = true;
+                    if (ANY_HIT) return true;
+                    tmax = t;
+                    tmax32 = up32(t - f.t_shift);
+                    prim = first + q;
+                    t_out = t; u_out = u; v_out = v;
+                }
+            }
         }
-        bool found = false;
-        while (st.sp > 0) {  // pop, skipping subtrees that begin beyond the current hit
+        cur = kDone;
+        while (st.sp > 0) {
+            int32_t ref;
             float tnear;
-            st.pop(cur, tnear);
-            if (tnear <= tmax32) { found = true; break; }
+            st.pop(ref, tnear);
+            if (tnear <= tmax32) { cur = ref; break; }
         }
-        if (!found) break;
     }
     return hit;
 }

@@ -12,12 +12,12 @@ struct PassDesc {
     int32_t dx, dy;
     int32_t band_rank, band_world;  // rows are cut into bands of 16; this process owns band b iff b % world == rank
     int32_t local_rows;             // image rows owned by this process
-    int32_t tiles_x;                // 8x8 pixel tiles per row of tiles
+    int32_t groups_x;               // 64x64-pixel groups (8x8 tiles of 8x8 pixels) per row of groups
     int32_t spp;                    // RaysPerPixel of the whole render
     int32_t sample_begin, sample_count;  // sample indices handled by this pass (each thread loops over them)
     int32_t max_depth;
-    int64_t tile_begin;             // first 8x8 tile (in local tile order) of this pass
-    int64_t n_pixels;               // tiles * 64 = threads of the primary launch
+    int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group
+    int64_t n_pixels;               // tiles * 64 = pixels (threads) of this pass
     uint32_t seed_lo, seed_hi;
 };
 

@@ -23,9 +23,18 @@ constexpr int kBlock = 256;
 #define RT_TRACE_BLOCK 64
 #endif
 constexpr int kTraceBlock = RT_TRACE_BLOCK;
+static_assert(kTraceBlock == 64, "k_primary maps one 8x8 pixel tile to one single-wave workgroup");
+
+// This lane's column of the dynamic-LDS traversal stack (see PairStack) and its depth in pairs.
+struct LdsStack {
+    int32_t* lds;
+    int stride;
+    int cap;
+};
+extern __shared__ int32_t dyn_lds[];
 // Waves per SIMD the traversal kernels are compiled for in fast mode (caps VGPRs at 512 / waves).
 #ifndef RT_FAST_WAVES
-#define RT_FAST_WAVES 4
+#define RT_FAST_WAVES 3
 #endif
 
 // ---- scene level intersection ---------------------------------------------------------------
@@ -37,7 +46,7 @@ struct SceneHit {
 
 template <int MODE>
 RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, VisitCounts& cnt,
-                              int32_t* lds, int stride);
+                              LdsStack ls);
 
 // Shape.Collide for one top-level shape.  Transformed shapes (shape_transformed_shape.go:26-57)
 // are unwound iteratively: the ray goes through each inverse transform (direction not
@@ -45,7 +54,7 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
 // normal come back through the forward transforms.
 template <int MODE>
 RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in, double tmin, double tmax, Col& c, int& prim,
-                          VisitCounts& cnt, int32_t* lds, int stride) {
+                          VisitCounts& cnt, LdsStack ls) {
     Ray r = r_in;
     int chain[4];
     int nchain = 0;
@@ -67,7 +76,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
         case RT_SHAPE_QUAD: hit = quad_collide(sc.quads[index], r, tmin, tmax, c); break;
         case RT_SHAPE_CYLINDER: hit = cylinder_collide(sc.cylinders[index], r, tmin, tmax, c); break;
         case RT_SHAPE_TRIANGLE: hit = tri_collide(sc.tris[index], r, tmin, tmax, c); break;
-        case RT_SHAPE_MESH: hit = mesh_node_collide<MODE>(sc, index, r, tmin, tmax, c, prim, cnt, lds, stride); break;
+        case RT_SHAPE_MESH: hit = mesh_node_collide<MODE>(sc, index, r, tmin, tmax, c, prim, cnt, ls); break;
         default: break;
     }
     if (hit) {
@@ -83,13 +92,13 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
 // Mesh.Collide for a top-level (untransformed) mesh node, attributes of the winning face included.
 template <int MODE>
 RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, VisitCounts& cnt,
-                              int32_t* lds, int stride) {
+                              LdsStack ls) {
     const DMesh& m = sc.meshes[index];
     double t, u, v;
     int p = 0;
     bool hit;
     if (MODE == RT_MODE_REFERENCE) hit = mesh_collide_ref(sc, m, r, tmin, tmax, p, t, u, v, cnt);
-    else hit = mesh_collide_fast<false>(sc, m, r, tmin, tmax, p, t, u, v, lds, stride, cnt);
+    else hit = mesh_collide_fast<false>(sc, m, r, tmin, tmax, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt);
     if (hit) {
         const double* pos = sc.prim_pos + (m.prim_off + p) * 9;
         prim = sc.prim_face[m.prim_off + p];
@@ -101,16 +110,15 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
 // The node loop of tracePath (render.go:155-169).  MESH_ONLY: the host has checked that every
 // node is a plain mesh, so the other shapes' code (and its registers) is left out.
 template <int MODE, bool MESH_ONLY = false>
-RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, int32_t* lds,
-                          int stride) {
+RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, LdsStack ls) {
     double min_dist = tmax;
     bool hit = false;
     for (int i = 0; i < sc.n_nodes; i++) {
         const DNode nd = sc.nodes[i];
         Col c;
         int prim;
-        const bool got = MESH_ONLY ? mesh_node_collide<MODE>(sc, nd.index, r, tmin, min_dist, c, prim, cnt, lds, stride)
-                                   : shape_collide<MODE>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, lds, stride);
+        const bool got = MESH_ONLY ? mesh_node_collide<MODE>(sc, nd.index, r, tmin, min_dist, c, prim, cnt, ls)
+                                   : shape_collide<MODE>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, ls);
         if (got && c.t < min_dist) {
             min_dist = c.t;
             h.c = c;
@@ -126,7 +134,7 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
 // the one whose shape was hit.  Reference mode runs the full closest-hit Collide per node as
 // the reference does; fast mode stops at the first face hit.
 template <int MODE>
-RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self_node, int32_t* lds, int stride) {
+RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self_node, LdsStack ls) {
     const DNode self = sc.nodes[self_node];
     VisitCounts cnt{0, 0};
     for (int i = 0; i < sc.n_nodes; i++) {
@@ -135,12 +143,12 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
         if (MODE == RT_MODE_FAST && nd.kind == RT_SHAPE_MESH) {
             double t, u, v;
             int p;
-            if (mesh_collide_fast<true>(sc, sc.meshes[nd.index], r, kEps, dist, p, t, u, v, lds, stride, cnt)) return true;
+            if (mesh_collide_fast<true>(sc, sc.meshes[nd.index], r, kEps, dist, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt)) return true;
             continue;
         }
         Col c;
         int prim;
-        if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, cnt, lds, stride)) return true;
+        if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, cnt, ls)) return true;
     }
     return false;
 }
@@ -277,10 +285,10 @@ RT_DEV void put_shade(const Queues& q, uint32_t slot, const Ray& r, const PathSt
 // Returns 0 = nothing further (invalid ray or miss), 1 = hit an emitting-only material
 // (`emission` set), 2 = hit needs Material.Resolve (`h` set).
 template <int MODE, bool MESH_ONLY>
-RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, uint32_t& n_left, int32_t* lds, int stride) {
+RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, uint32_t& n_left, LdsStack ls) {
     if (bad3(r.o) || bad3(r.d)) return 0;  // render.go:147-150
     VisitCounts cnt{0, 0};
-    if (!scene_closest<MODE, MESH_ONLY>(sc, r, kEps, kMaxFloat, h, cnt, lds, stride)) {
+    if (!scene_closest<MODE, MESH_ONLY>(sc, r, kEps, kMaxFloat, h, cnt, ls)) {
         n_left++;
         return 0;
     }
@@ -298,14 +306,19 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // loop = the pass's sample indices.
 template <int MODE, bool MESH_ONLY>
 __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_primary(DScene sc, DCamera cam, PassDesc pass, Queues q, double* __restrict__ film) {
-    __shared__ int32_t lds[MODE == RT_MODE_FAST ? 2 * kLdsPairs * kTraceBlock : 1];
-    const int64_t g = (int64_t)blockIdx.x * kTraceBlock + threadIdx.x;
-    const int p = (int)(g & 63);
-    const int64_t tile = pass.tile_begin + (g >> 6);
-    const int lx = (int)(tile % pass.tiles_x) * 8 + (p & 7);
-    const int ly = (int)(tile / pass.tiles_x) * 8 + (p >> 3);
+    // Workgroup b runs on XCD b % 8.  Tiles are numbered group by group (8x8 tiles = 64x64 pixels) and every
+    // group is traced by one XCD, so the rays an XCD has in flight share BVH nodes in its L2; consecutive groups
+    // go to consecutive XCDs, which keeps empty parts of the image from idling one of them.
+    const uint32_t j = blockIdx.x >> 3;
+    const int64_t v = ((int64_t)(j >> 6) * 8 + (blockIdx.x & 7)) * 64 + (j & 63);
+    const int p = (int)threadIdx.x;
+    const int64_t tile = pass.tile_begin + v;
+    const int64_t group = tile >> 6;
+    const int w = (int)(tile & 63);
+    const int lx = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8 + (p & 7);
+    const int ly = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8 + (p >> 3);
     const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
-    const bool live = g < pass.n_pixels && lx < pass.dx && ly < pass.local_rows && row < pass.dy;
+    const bool live = v * 64 < pass.n_pixels && lx < pass.dx && ly < pass.local_rows && row < pass.dy;
     const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
     const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
     V3 acc = mk(0, 0, 0);
@@ -329,7 +342,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
             r = camera_cast(cam, fs, ft, rng);
             n_total++;
             V3 em;
-            const int what = trace_one<MODE, MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, lds + threadIdx.x, kTraceBlock);
+            const int what = trace_one<MODE, MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
             if (what == 1) acc = acc + em;
             want = what == 2;
             ps.rad = mk(1, 1, 1);
@@ -352,7 +365,6 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
 
 template <int MODE, bool MESH_ONLY>
 __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_trace(DScene sc, Queues q, uint32_t n, double* __restrict__ film) {
-    __shared__ int32_t lds[MODE == RT_MODE_FAST ? 2 * kLdsPairs * kTraceBlock : 1];
     const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = i < n;
     bool want = false;
@@ -369,7 +381,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
         ps.path = q.rays.path[i];
         ps.depth_n = q.rays.depth_n[i];
         V3 em;
-        const int what = trace_one<MODE, MESH_ONLY>(sc, r, ps.rad, h, em, n_left, lds + threadIdx.x, kTraceBlock);
+        const int what = trace_one<MODE, MESH_ONLY>(sc, r, ps.rad, h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
         if (what == 1) film_add(film, ps.pixel, em);
         want = what == 2;
     }
@@ -466,9 +478,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, PassDesc pass, Queu
 // ComputeDirectLighting's loop body for one (surface point, light) pair
 // (material_lambertian.go:23-52, material_metal.go:68-106, material_dielectric.go:128-170).
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_direct(DScene sc, Queues q, uint32_t n_surf, double* __restrict__ film) {
-    __shared__ int32_t lds[MODE == RT_MODE_FAST ? 2 * kLdsPairs * kBlock : 1];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+__global__ void __launch_bounds__(kTraceBlock) k_direct(DScene sc, Queues q, uint32_t n_surf, double* __restrict__ film) {
+    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = i < n_surf;
     {
         const unsigned long long mask = __ballot(live);
@@ -484,7 +495,7 @@ __global__ void __launch_bounds__(kBlock) k_direct(DScene sc, Queues q, uint32_t
     dir = dir / dist;
     const V3 wi = m.kind == RT_MAT_LAMBERTIAN ? dir : unit(dir);
     Ray sh{p + n * kEps, wi};
-    if (scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], lds + threadIdx.x, kBlock)) return;
+    if (scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs})) return;
     V3 contrib;
     if (m.kind == RT_MAT_LAMBERTIAN) {
         const double ndl = go_max(0, dot(n, dir));
@@ -526,10 +537,9 @@ __global__ void __launch_bounds__(kBlock) k_resolve(const double* __restrict__ f
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_intersect_batch(DScene sc, const double* __restrict__ o, const double* __restrict__ d, uint64_t n,
+__global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DScene sc, const double* __restrict__ o, const double* __restrict__ d, uint64_t n,
                                                            double tmin, double tmax, rt_hit* __restrict__ hits) {
-    __shared__ int32_t lds[MODE == RT_MODE_FAST ? 2 * kLdsPairs * kBlock : 1];
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i >= n) return;
     Ray r{ld3(o + 3 * i), ld3(d + 3 * i)};
     SceneHit sh;
@@ -540,7 +550,7 @@ __global__ void __launch_bounds__(kBlock) k_intersect_batch(DScene sc, const dou
     h.t = 0;
     for (int k = 0; k < 3; k++) { h.at[k] = 0; h.normal[k] = 0; }
     h.uv[0] = h.uv[1] = 0;
-    if (scene_closest<MODE>(sc, r, tmin, tmax, sh, cnt, lds + threadIdx.x, kBlock)) {
+    if (scene_closest<MODE>(sc, r, tmin, tmax, sh, cnt, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs})) {
         h.node = sh.node;
         h.prim = sh.prim;
         h.t = sh.c.t;
@@ -567,29 +577,36 @@ __global__ void __launch_bounds__(kBlock) k_cast_batch(DCamera cam, const double
 // ---- launchers ---------------------------------------------------------------------------------
 
 static inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+static inline unsigned trace_blocks(uint64_t n) { return (unsigned)((n + kTraceBlock - 1) / kTraceBlock); }
+// dynamic LDS of a traversal launch: the per-lane stack of (reference, distance) pairs, fast mode only
+static inline size_t stack_bytes(const DScene& sc, int mode) {
+    return mode == RT_MODE_FAST ? (size_t)2 * sc.stack_pairs * kTraceBlock * sizeof(int32_t) : 0;
+}
 
 void launch_primary(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, int mode, bool mesh_only, double* film,
                     hipStream_t s) {
     if (pass.n_pixels == 0 || pass.sample_count == 0) return;
-    const dim3 grid((unsigned)(((uint64_t)pass.n_pixels + kTraceBlock - 1) / kTraceBlock)), block(kTraceBlock);
+    const dim3 grid((trace_blocks((uint64_t)pass.n_pixels) + 511u) & ~511u), block(kTraceBlock);  // whole groups on all 8 XCDs
+    const size_t lds = stack_bytes(sc, mode);
     if (mode == RT_MODE_REFERENCE) {
-        if (mesh_only) hipLaunchKernelGGL((k_primary<RT_MODE_REFERENCE, true>), grid, block, 0, s, sc, cam, pass, q, film);
-        else hipLaunchKernelGGL((k_primary<RT_MODE_REFERENCE, false>), grid, block, 0, s, sc, cam, pass, q, film);
+        if (mesh_only) hipLaunchKernelGGL((k_primary<RT_MODE_REFERENCE, true>), grid, block, lds, s, sc, cam, pass, q, film);
+        else hipLaunchKernelGGL((k_primary<RT_MODE_REFERENCE, false>), grid, block, lds, s, sc, cam, pass, q, film);
     } else {
-        if (mesh_only) hipLaunchKernelGGL((k_primary<RT_MODE_FAST, true>), grid, block, 0, s, sc, cam, pass, q, film);
-        else hipLaunchKernelGGL((k_primary<RT_MODE_FAST, false>), grid, block, 0, s, sc, cam, pass, q, film);
+        if (mesh_only) hipLaunchKernelGGL((k_primary<RT_MODE_FAST, true>), grid, block, lds, s, sc, cam, pass, q, film);
+        else hipLaunchKernelGGL((k_primary<RT_MODE_FAST, false>), grid, block, lds, s, sc, cam, pass, q, film);
     }
 }
 
 void launch_trace(const DScene& sc, const Queues& q, uint32_t n, int mode, bool mesh_only, double* film, hipStream_t s) {
     if (n == 0) return;
-    const dim3 grid((n + kTraceBlock - 1) / kTraceBlock), block(kTraceBlock);
+    const dim3 grid(trace_blocks(n)), block(kTraceBlock);
+    const size_t lds = stack_bytes(sc, mode);
     if (mode == RT_MODE_REFERENCE) {
-        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true>), grid, block, 0, s, sc, q, n, film);
-        else hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, false>), grid, block, 0, s, sc, q, n, film);
+        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true>), grid, block, lds, s, sc, q, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, false>), grid, block, lds, s, sc, q, n, film);
     } else {
-        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, true>), grid, block, 0, s, sc, q, n, film);
-        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false>), grid, block, 0, s, sc, q, n, film);
+        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, true>), grid, block, lds, s, sc, q, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false>), grid, block, lds, s, sc, q, n, film);
     }
 }
 
@@ -600,11 +617,11 @@ void launch_shade(const DScene& sc, const PassDesc& pass, const Queues& q, uint3
 
 void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode, double* film, hipStream_t s) {
     if (n_surf == 0 || sc.n_lights == 0) return;
-    dim3 grid(blocks_for(n_surf), (unsigned)sc.n_lights);
+    dim3 grid(trace_blocks(n_surf), (unsigned)sc.n_lights);
     if (mode == RT_MODE_REFERENCE)
-        hipLaunchKernelGGL(k_direct<RT_MODE_REFERENCE>, grid, dim3(kBlock), 0, s, sc, q, n_surf, film);
+        hipLaunchKernelGGL(k_direct<RT_MODE_REFERENCE>, grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, film);
     else
-        hipLaunchKernelGGL(k_direct<RT_MODE_FAST>, grid, dim3(kBlock), 0, s, sc, q, n_surf, film);
+        hipLaunchKernelGGL(k_direct<RT_MODE_FAST>, grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, film);
 }
 
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s) {
@@ -616,9 +633,10 @@ void launch_intersect_batch(const DScene& sc, const double* o, const double* d, 
                             rt_hit* hits, hipStream_t s) {
     if (n == 0) return;
     if (mode == RT_MODE_REFERENCE)
-        hipLaunchKernelGGL(k_intersect_batch<RT_MODE_REFERENCE>, dim3(blocks_for(n)), dim3(kBlock), 0, s, sc, o, d, n, tmin, tmax, hits);
+        hipLaunchKernelGGL(k_intersect_batch<RT_MODE_REFERENCE>, dim3(trace_blocks(n)), dim3(kTraceBlock), 0, s, sc, o, d, n, tmin, tmax, hits);
     else
-        hipLaunchKernelGGL(k_intersect_batch<RT_MODE_FAST>, dim3(blocks_for(n)), dim3(kBlock), 0, s, sc, o, d, n, tmin, tmax, hits);
+        hipLaunchKernelGGL(k_intersect_batch<RT_MODE_FAST>, dim3(trace_blocks(n)), dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, o, d, n, tmin,
+                           tmax, hits);
 }
 
 void launch_cast_batch(const DCamera& cam, const double* st, const uint32_t* pixel_sample, uint64_t n, uint32_t seed_lo,

@@ -209,12 +209,12 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     pass.band_rank = rank;
     pass.band_world = world;
     pass.local_rows = local_rows;
-    pass.tiles_x = (o->dx + 7) / 8;
+    pass.groups_x = (o->dx + 63) / 64;
     pass.spp = o->rays_per_pixel;
     pass.seed_lo = (uint32_t)((uint64_t)o->seed & 0xffffffffu);
     pass.seed_hi = (uint32_t)((uint64_t)o->seed >> 32);
     pass.max_depth = o->max_ray_depth;
-    const int64_t tiles_total = (int64_t)pass.tiles_x * ((local_rows + 7) / 8);
+    const int64_t tiles_total = (int64_t)pass.groups_x * ((local_rows + 63) / 64) * 64;  // whole groups; tiles outside the image idle
     const int s_first = o->sample_count > 0 ? o->sample_begin : 0;
     const int s_end = o->sample_count > 0 ? o->sample_begin + o->sample_count : o->rays_per_pixel;
     // paths per primary launch: bounded by the shade queue unless nothing is ever queued
@@ -222,7 +222,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
 
     HIP_TRY(hipMemsetAsync(q.counters, 0, sizeof(Counters), stream));
     EventPool events;
-    uint64_t traverse_launches = 0, traverse_rays = 0;
+    uint64_t traverse_launches = 0;
     Counters host{};
     uint64_t pool_top = 0;
 
@@ -261,7 +261,6 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             HIP_TRY(hipEventRecord(ev->b, stream));
             HIP_TRY(hipGetLastError());
             traverse_launches++;
-            traverse_rays += (uint64_t)pass.n_pixels * (uint64_t)s_count;
             if (sc->all_terminal) {
                 if (events.used >= 256) {  // bound the number of live events without stalling every pass
                     HIP_TRY(hipStreamSynchronize(stream));
@@ -314,7 +313,6 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                 HIP_TRY(hipEventRecord(ev->b, stream));
                 HIP_TRY(hipGetLastError());
                 traverse_launches++;
-                traverse_rays += n;
                 n_traced = n;
             }
         }
@@ -330,7 +328,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         stats->traverse_seconds = events.ms * 1e-3;
         stats->traverse_launches = traverse_launches;
-        stats->traverse_rays = traverse_rays;
+        stats->traverse_rays = host.total;  // every counted ray went through exactly one of the timed launches
     }
     return RT_OK;
 }

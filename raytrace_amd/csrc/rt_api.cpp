@@ -182,6 +182,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         const rt_mesh& m = d->meshes[i];
         if (m.n_faces == 0) return fail(RT_ERR_INVALID, "Mesh must contain at least one face");
         if (m.first_face + m.n_faces > d->n_faces || m.n_faces > 0x7fffffffull) return fail(RT_ERR_INVALID, "mesh face range out of bounds");
+        if (m.n_faces >= ((uint64_t)1 << 28) - 16) return fail(RT_ERR_UNSUPPORTED, "meshes above 2^28 faces are not supported");
     }
     for (uint64_t i = 0; i < d->n_materials; i++) {
         const rt_material& m = d->materials[i];
@@ -252,11 +253,13 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<RefNode> ref_nodes;
     std::vector<FastNode> fast_nodes;
     std::vector<double> prim_pos;
+    std::vector<Tri32> prim_tri32;
     std::vector<int32_t> prim_face;
     std::vector<double> face_uv(d->n_faces * 6);
     for (uint64_t i = 0; i < d->n_faces; i++)
         for (int v = 0; v < 3; v++) { face_uv[i * 6 + v * 2] = d->faces[i].v[v][3]; face_uv[i * 6 + v * 2 + 1] = d->faces[i].v[v][4]; }
     sc->bvh_info.resize(d->n_meshes);
+    int32_t stack_pairs = 2;
     for (uint64_t i = 0; i < d->n_meshes; i++) {
         MeshBvh b;
         build_mesh_bvh(d->faces + d->meshes[i].first_face, d->meshes[i].n_faces, b);
@@ -268,12 +271,16 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         std::memcpy(m.center, b.center, sizeof(m.center));
         std::memcpy(m.root_box, b.root_box, sizeof(m.root_box));
         m.pad = b.pad;
+        m.radius = b.radius;
+        m.pad2 = 0;
         m.n_faces = (int32_t)d->meshes[i].n_faces;
         ref_nodes.insert(ref_nodes.end(), b.ref_nodes.begin(), b.ref_nodes.end());
         fast_nodes.insert(fast_nodes.end(), b.fast_nodes.begin(), b.fast_nodes.end());
         prim_pos.insert(prim_pos.end(), b.prim_pos.begin(), b.prim_pos.end());
+        prim_tri32.insert(prim_tri32.end(), b.prim_tri32.begin(), b.prim_tri32.end());
         prim_face.insert(prim_face.end(), b.prim_face.begin(), b.prim_face.end());
         sc->bvh_info[i] = b.info;
+        stack_pairs = std::max(stack_pairs, b.fast_depth + 1);
     }
     std::vector<rt_material> materials(d->materials, d->materials + d->n_materials);
     std::vector<rt_texture> textures(d->textures, d->textures + d->n_textures);
@@ -298,6 +305,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HIP_TRY(sc->mem.upload(ref_nodes, &dev.ref_nodes));
     HIP_TRY(sc->mem.upload(fast_nodes, &dev.fast_nodes));
     HIP_TRY(sc->mem.upload(prim_pos, &dev.prim_pos));
+    HIP_TRY(sc->mem.upload(prim_tri32, &dev.prim_tri32));
     HIP_TRY(sc->mem.upload(prim_face, &dev.prim_face));
     HIP_TRY(sc->mem.upload(face_uv, &dev.face_uv));
     HIP_TRY(sc->mem.upload(materials, &dev.materials));
@@ -312,6 +320,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         if (n.kind != RT_SHAPE_MESH) sc->mesh_only = false;
     dev.n_nodes = (int32_t)d->n_nodes;
     dev.n_lights = (int32_t)d->n_lights;
+    dev.stack_pairs = stack_pairs;
+    dev.pad = 0;
     *out = sc.release();
     return RT_OK;
 }

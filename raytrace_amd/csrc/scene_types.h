@@ -60,7 +60,9 @@ struct DMesh {
     double center[3];
     double root_box[6];
     float pad;
+    float radius;  // largest |coordinate| in the mesh frame (error bound of the float32 face pre-test)
     int32_t n_faces;
+    int32_t pad2;
 };
 
 struct DImage {
@@ -79,6 +81,7 @@ struct DScene {
     const RefNode* ref_nodes;
     const FastNode* fast_nodes;
     const double* prim_pos;    // 9 per prim, leaf order
+    const Tri32* prim_tri32;   // leaf order
     const int32_t* prim_face;  // leaf order -> face index within its mesh
     const double* face_uv;     // 6 per face, caller order
     const rt_material* materials;
@@ -86,6 +89,8 @@ struct DScene {
     const DImage* images;
     const rt_light* lights;
     int32_t n_nodes, n_lights;
+    int32_t stack_pairs;  // depth of the deepest fast tree + 1: capacity of the LDS traversal stack
+    int32_t pad;
 };
 
 struct DCamera {
