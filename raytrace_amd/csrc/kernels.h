@@ -16,6 +16,7 @@ struct PassDesc {
     int32_t spp;                    // RaysPerPixel of the whole render
     int32_t sample_begin, sample_count;  // sample indices handled by this pass (each thread loops over them)
     int32_t max_depth;
+    int32_t chunk;                  // sample indices per work item of the primary launch (item = tile x chunk)
     int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group
     int64_t n_pixels;               // tiles * 64 = pixels (threads) of this pass
     uint32_t seed_lo, seed_hi;

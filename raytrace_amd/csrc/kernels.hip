@@ -302,65 +302,94 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 
 // ---- kernels -----------------------------------------------------------------------------------
 
-// renderPixel (render.go:186-217) for one pass: thread = pixel (8x8 tiles, one tile per wave),
-// loop = the pass's sample indices.
+// renderPixel (render.go:186-217) for one pass.  Persistent single-wave workgroups: each wave pulls
+// work items from a queue until the pass is drained.  An item is an 8x8-pixel tile (thread = pixel) and a
+// run of pass.chunk sample indices: small enough that the slowest items (silhouette tiles cost >10x the
+// mean) cannot leave most of the chip idle at the end of the launch.  Tiles are numbered group by group (8x8 tiles = 64x64 pixels); group g
+// belongs to the queue of XCD g % 8, so the rays an XCD has in flight share BVH nodes in its L2, and a wave
+// whose own queue is empty takes tiles from the other XCDs' queues.  The queue cursors only grow, so every
+// wave reaches the exit after finding all eight queues exhausted.
 template <int MODE, bool MESH_ONLY>
 __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_primary(DScene sc, DCamera cam, PassDesc pass, Queues q, double* __restrict__ film) {
-    // Workgroup b runs on XCD b % 8.  Tiles are numbered group by group (8x8 tiles = 64x64 pixels) and every
-    // group is traced by one XCD, so the rays an XCD has in flight share BVH nodes in its L2; consecutive groups
-    // go to consecutive XCDs, which keeps empty parts of the image from idling one of them.
-    const uint32_t j = blockIdx.x >> 3;
-    const int64_t v = ((int64_t)(j >> 6) * 8 + (blockIdx.x & 7)) * 64 + (j & 63);
     const int p = (int)threadIdx.x;
-    const int64_t tile = pass.tile_begin + v;
-    const int64_t group = tile >> 6;
-    const int w = (int)(tile & 63);
-    const int lx = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8 + (p & 7);
-    const int ly = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8 + (p >> 3);
-    const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
-    const bool live = v * 64 < pass.n_pixels && lx < pass.dx && ly < pass.local_rows && row < pass.dy;
-    const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
-    const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
-    V3 acc = mk(0, 0, 0);
+    const int64_t n_tiles = pass.n_pixels >> 6;
+    const uint32_t n_chunks = (uint32_t)((pass.sample_count + pass.chunk - 1) / pass.chunk);
+    const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
     uint32_t n_total = 0, n_left = 0;
-    for (int k = 0; k < pass.sample_count; k++) {
-        const int s = pass.sample_begin + k;
-        bool want = false;
-        Ray r;
-        SceneHit h;
-        PathState ps;
-        if (live) {
-            Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(y * pass.dx + lx), (uint32_t)s, 1u, 0u};
-            double fs, ft;
-            if (pass.spp == 1) {  // render.go:202-210
-                fs = ((double)lx + 0.5) / (double)pass.dx;
-                ft = ((double)y + 0.5) / (double)pass.dy;
-            } else {
-                fs = ((double)lx + rng.float64()) / (double)pass.dx;
-                ft = ((double)y + rng.float64()) / (double)pass.dy;
+    for (;;) {
+        long long v = -1;
+        uint32_t chunk = 0;
+        if (p == 0) {
+            for (uint32_t k = 0; k < 8 && v < 0; k++) {
+                const uint32_t owner = (xcd + k) & 7;
+                const uint32_t item = atomicAdd(&q.counters->tile_cursor[owner], 1u);
+                const uint32_t idx = item / n_chunks;
+                const long long cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
+                if (cand < n_tiles) {
+                    v = cand;
+                    chunk = item - idx * n_chunks;
+                }
             }
-            r = camera_cast(cam, fs, ft, rng);
-            n_total++;
-            V3 em;
-            const int what = trace_one<MODE, MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
-            if (what == 1) acc = acc + em;
-            want = what == 2;
-            ps.rad = mk(1, 1, 1);
-            ps.pixel = pixel;
-            ps.sample = (uint32_t)s;
-            ps.path = 1;
-            ps.depth_n = rng.n;
         }
-        const uint32_t slot = wave_append(&q.counters->shade_count, want);
-        if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
+        v = __shfl(v, 0, 64);
+        if (v < 0) break;
+        chunk = __shfl(chunk, 0, 64);
+        const int k_begin = (int)chunk * pass.chunk;
+        const int k_end = k_begin + pass.chunk < pass.sample_count ? k_begin + pass.chunk : pass.sample_count;
+        const int64_t tile = pass.tile_begin + v;
+        const int64_t group = tile >> 6;
+        const int w = (int)(tile & 63);
+        const int lx = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8 + (p & 7);
+        const int ly = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8 + (p >> 3);
+        const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
+        const bool live = lx < pass.dx && ly < pass.local_rows && row < pass.dy;
+        if (__ballot(live) == 0) continue;
+        const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
+        const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
+        V3 acc = mk(0, 0, 0);
+        for (int k = k_begin; k < k_end; k++) {
+            const int s = pass.sample_begin + k;
+            bool want = false;
+            Ray r;
+            SceneHit h;
+            PathState ps;
+            if (live) {
+                Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(y * pass.dx + lx), (uint32_t)s, 1u, 0u};
+                double fs, ft;
+                if (pass.spp == 1) {  // render.go:202-210
+                    fs = ((double)lx + 0.5) / (double)pass.dx;
+                    ft = ((double)y + 0.5) / (double)pass.dy;
+                } else {
+                    fs = ((double)lx + rng.float64()) / (double)pass.dx;
+                    ft = ((double)y + rng.float64()) / (double)pass.dy;
+                }
+                r = camera_cast(cam, fs, ft, rng);
+                n_total++;
+                V3 em;
+                const int what = trace_one<MODE, MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
+                if (what == 1) acc = acc + em;
+                want = what == 2;
+                ps.rad = mk(1, 1, 1);
+                ps.pixel = pixel;
+                ps.sample = (uint32_t)s;
+                ps.path = 1;
+                ps.depth_n = rng.n;
+            }
+            const uint32_t slot = wave_append(&q.counters->shade_count, want);
+            if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
+        }
+        if (live) {
+            if (n_chunks == 1) {  // this wave is the only writer of the pixel during the launch
+                double* f = film + (size_t)pixel * 3;
+                if (acc.x != 0) f[0] += acc.x;
+                if (acc.y != 0) f[1] += acc.y;
+                if (acc.z != 0) f[2] += acc.z;
+            } else {
+                film_add(film, pixel, acc);
+            }
+        }
     }
     wave_tally(q.counters, n_total, n_left, 0);
-    if (live) {  // this launch is the only writer of this pixel while it runs: plain read-modify-write
-        double* f = film + (size_t)pixel * 3;
-        if (acc.x != 0) f[0] += acc.x;
-        if (acc.y != 0) f[1] += acc.y;
-        if (acc.z != 0) f[2] += acc.z;
-    }
 }
 
 template <int MODE, bool MESH_ONLY>
@@ -583,17 +612,35 @@ static inline size_t stack_bytes(const DScene& sc, int mode) {
     return mode == RT_MODE_FAST ? (size_t)2 * sc.stack_pairs * kTraceBlock * sizeof(int32_t) : 0;
 }
 
+// Resident single-wave workgroups of a k_primary variant on the current device, rounded down to whole
+// rounds over the 8 XCDs.
+template <typename K>
+static unsigned persistent_grid(K kernel, size_t lds) {
+    int device = 0, cus = 0, per_cu = 0;
+    (void)hipGetDevice(&device);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kTraceBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] primary: %d CUs x %d workgroups, %zu B LDS each\n", cus, per_cu, lds);
+    const unsigned n = (unsigned)std::max(cus, 8) * (unsigned)per_cu;
+    return n & ~7u;
+}
+
 void launch_primary(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, int mode, bool mesh_only, double* film,
                     hipStream_t s) {
-    if (pass.n_pixels == 0 || pass.sample_count == 0) return;
-    const dim3 grid((trace_blocks((uint64_t)pass.n_pixels) + 511u) & ~511u), block(kTraceBlock);  // whole groups on all 8 XCDs
+    if (pass.n_pixels <= 0) return;
     const size_t lds = stack_bytes(sc, mode);
+    const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
+    auto go = [&](auto kernel) {
+        const unsigned resident = persistent_grid(kernel, lds);
+        const dim3 grid(std::min(resident, (tiles + 7u) & ~7u)), block(kTraceBlock);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, sc, cam, pass, q, film);
+    };
     if (mode == RT_MODE_REFERENCE) {
-        if (mesh_only) hipLaunchKernelGGL((k_primary<RT_MODE_REFERENCE, true>), grid, block, lds, s, sc, cam, pass, q, film);
-        else hipLaunchKernelGGL((k_primary<RT_MODE_REFERENCE, false>), grid, block, lds, s, sc, cam, pass, q, film);
+        if (mesh_only) go(k_primary<RT_MODE_REFERENCE, true>);
+        else go(k_primary<RT_MODE_REFERENCE, false>);
     } else {
-        if (mesh_only) hipLaunchKernelGGL((k_primary<RT_MODE_FAST, true>), grid, block, lds, s, sc, cam, pass, q, film);
-        else hipLaunchKernelGGL((k_primary<RT_MODE_FAST, false>), grid, block, lds, s, sc, cam, pass, q, film);
+        if (mesh_only) go(k_primary<RT_MODE_FAST, true>);
+        else go(k_primary<RT_MODE_FAST, false>);
     }
 }
 

@@ -8,6 +8,7 @@
 // leaves k_primary and is rendered without a single host synchronisation per pass.
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
@@ -232,11 +233,13 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         HIP_TRY(events.drain());
         return RT_OK;
     };
-    auto reset_cursors = [&]() -> int {  // zero the three append cursors, keep the statistics
-        HIP_TRY(hipMemsetAsync(&q.counters->shade_count, 0, 3 * sizeof(unsigned int), stream));
+    auto reset_cursors = [&]() -> int {  // zero the append and tile cursors, keep the statistics
+        HIP_TRY(hipMemsetAsync(&q.counters->shade_count, 0, sizeof(Counters) - offsetof(Counters, shade_count), stream));
         return RT_OK;
     };
 
+    int chunk_override = 0;  // RT_CHUNK: tuning knob for the samples per work item
+    if (const char* e = getenv("RT_CHUNK")) chunk_override = std::max(1, atoi(e));
     for (int s0 = s_first; s0 < s_end;) {
         // a pass covers all tiles for a run of samples when that fits, else a run of tiles for one sample
         int s_count = 1;
@@ -251,6 +254,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             const int64_t nt = std::min(tiles_per_launch, tiles_total - t0);
             pass.sample_begin = s0;
             pass.sample_count = s_count;
+            pass.chunk = chunk_override > 0 ? chunk_override : (s_count >= 32 ? 4 : (s_count >= 2 ? 2 : 1));
             pass.tile_begin = t0;
             pass.n_pixels = nt * 64;
             if (int rc = reset_cursors()) return rc;

@@ -148,6 +148,7 @@ struct Counters {
     unsigned long long total, exceeded, left, shadow;  // RenderStats (render.go:38-45) + occlusion rays
     unsigned int shade_count, next_count, surf_count;  // append cursors of the three queues
     unsigned int pad;
+    unsigned int tile_cursor[8];  // next tile of each XCD's share of a primary launch
 };
 
 }  // namespace rt

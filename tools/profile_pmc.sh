@@ -6,8 +6,10 @@ OUT="$REPO/gpurun_out/pmc"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 0 --spp-step 16 --no-cpu-baseline"
+ONLY="$*"   # optional list of pass names; default all
 run() {
   name=$1; shift
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return 0; fi
   timeout -s KILL 180 rocprofv3 --pmc "$@" -d "$OUT/$name" -o pmc --output-format csv -- python3 "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; exit 1; }
   echo "pass $name done"
 }
@@ -18,3 +20,4 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
