@@ -199,8 +199,8 @@ struct Flattener {
 
     void set_box(FastNode& f, int k, const Box& b) {
         for (int a = 0; a < 3; a++) {
-            f.lo[k][a] = round_down(b.mn[a] - out.center[a]) - out.pad;
-            f.hi[k][a] = round_up(b.mx[a] - out.center[a]) + out.pad;
+            f.b[k][a][0] = round_down(b.mn[a] - out.center[a]) - out.pad;
+            f.b[k][a][1] = round_up(b.mx[a] - out.center[a]) + out.pad;
         }
     }
     Box range_box(uint32_t first, uint32_t count) const {
@@ -303,7 +303,7 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
         fl.set_box(f, 0, root->box);
         f.child[0] = ref;
         f.child[1] = kFastEmpty;
-        for (int a = 0; a < 3; a++) { f.lo[1][a] = 1.0f; f.hi[1][a] = -1.0f; }
+        for (int a = 0; a < 3; a++) { f.b[1][a][0] = 1.0f; f.b[1][a][1] = -1.0f; }
         out.fast_nodes[0] = f;
     }
 

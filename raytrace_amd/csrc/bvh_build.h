@@ -28,8 +28,7 @@ static_assert(sizeof(RefNode) == 64, "RefNode layout");
 // reference tree are cut into runs of <= 8 prims under extra inner nodes).
 constexpr int32_t kFastEmpty = INT32_MIN;
 struct FastNode {
-    float lo[2][3];
-    float hi[2][3];
+    float b[2][3][2];  // [child][axis][0 = min, 1 = max]: the two planes of a slab are adjacent for packed math
     int32_t child[2];
     int32_t pad[2];
 };

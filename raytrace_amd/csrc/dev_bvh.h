@@ -82,11 +82,24 @@ RT_DEV bool mesh_collide_ref(const DScene& sc, const DMesh& m, const Ray& r, dou
 // nearest first.  `stack` is this lane's column of an LDS array: entry i lives at
 // stack[i * stride].
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct FastRay {
     float ox, oy, oz;
-    float ix, iy, iz;  // 1 / direction
-    double t_shift;    // the float32 ray starts at o + d * t_shift
+    float ix, iy, iz;     // 1 / direction, magnitude capped at 2^90 (see slab_inverse)
+    float nx, ny, nz;     // -o * (1 / direction): a slab distance is one fused multiply-add, plane * i + n
+    double t_shift;       // the float32 ray starts at o + d * t_shift
 };
+
+// 1 / d with |result| <= 2^90, so that every slab product stays finite.  For a direction component
+// smaller than 2^-90 the slab then spans |t| >= 2^90 * (distance from the origin to the nearer plane),
+// and that distance is at least most of the box padding for any ray the unpadded box contains: far
+// beyond every t a traversal compares with, so the cap never culls such a ray.
+RT_DEV float slab_inverse(float d) {
+    const float cap = 1.2379400392853803e27f;  // 2^90
+    const float inv = 1.0f / d;
+    return fabsf(inv) <= cap ? inv : copysignf(cap, d);
+}
 
 // Root-box clip in float64 and set-up of the float32 ray in the mesh frame.
 RT_DEV bool fast_setup(const DMesh& m, const Ray& r, double tmin, double tmax, FastRay& f) {
@@ -106,7 +119,8 @@ RT_DEV bool fast_setup(const DMesh& m, const Ray& r, double tmin, double tmax, F
     f.t_shift = t_in > 0 ? t_in : 0;
     V3 ol = (r.o + r.d * f.t_shift) - ld3(m.center);
     f.ox = (float)ol.x; f.oy = (float)ol.y; f.oz = (float)ol.z;
-    f.ix = 1.0f / (float)r.d.x; f.iy = 1.0f / (float)r.d.y; f.iz = 1.0f / (float)r.d.z;
+    f.ix = slab_inverse((float)r.d.x); f.iy = slab_inverse((float)r.d.y); f.iz = slab_inverse((float)r.d.z);
+    f.nx = -f.ox * f.ix; f.ny = -f.oy * f.iy; f.nz = -f.oz * f.iz;
     return true;
 }
 
@@ -153,6 +167,7 @@ constexpr float kErr = 64.0f * 5.9604645e-8f;  // 64 * 2^-24
 
 RT_DEV bool tri32_rejects(const Tri32& t, const FastRay& f, float dx, float dy, float dz, float err_r /* kErr * |d| * R */,
                           float err_d /* kErr * |d| */) {
+#pragma clang fp contract(fast)  // fusing only removes roundings: the error bounds above still hold
     const float hx = dy * t.e2[2] - dz * t.e2[1], hy = dz * t.e2[0] - dx * t.e2[2], hz = dx * t.e2[1] - dy * t.e2[0];
     const float a = t.e1[0] * hx + t.e1[1] * hy + t.e1[2] * hz;
     const float sx = f.ox - t.p0[0], sy = f.oy - t.p0[1], sz = f.oz - t.p0[2];
@@ -198,12 +213,13 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
             bool go[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const float x0 = (n.lo[k][0] - f.ox) * f.ix, x1 = (n.hi[k][0] - f.ox) * f.ix;
-                const float y0 = (n.lo[k][1] - f.oy) * f.iy, y1 = (n.hi[k][1] - f.oy) * f.iy;
-                const float z0 = (n.lo[k][2] - f.oz) * f.iz, z1 = (n.hi[k][2] - f.oz) * f.iz;
-                // fminf / fmaxf return the other operand for a NaN (0 * inf on an in-plane axis): not constraining
-                const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin32));
-                const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax32));
+                // both planes of a slab in one packed fused multiply-add; the rounding of n and of the sum moves a
+                // plane by a few 2^-24 of the mesh radius, well inside the padding of the boxes
+                const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][0], n.b[k][0][1]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
+                const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][0], n.b[k][1][1]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
+                const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][0], n.b[k][2][1]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
+                const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), tmin32));
+                const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), tmax32));
                 tn[k] = tnear;
                 go[k] = (tnear <= tfar) && n.child[k] != kFastEmpty;
             }
