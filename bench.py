@@ -98,7 +98,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from raytrace_amd import _lib, abi, phys, scenes
+    from raytrace_amd import _lib, abi, phys, scenes, shard
 
     lib = _lib.load(local_rank)
     scene = scenes.scan(level=a.level, dx=a.dx, dy=a.dy, spp=a.spp, depth=10, seed=0, tex_size=a.tex)
@@ -138,16 +138,12 @@ def main():
         trav_s += st.traverse_seconds
         trav_launches += st.traverse_launches
         trav_rays += st.traverse_rays
-    if world > 1:  # the per-GPU films hold disjoint row bands: one sum onto rank 0 combines them
-        dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+    shard.combine_films(film)  # the per-GPU films hold disjoint row bands: one sum onto rank 0 assembles the frame
     fence()
     elapsed = time.perf_counter() - t_begin
     tot = torch.tensor([rays, elapsed, trav_s, float(trav_launches), float(trav_rays)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[1])
+    tot, mx = shard.combine_counters(tot)
+    elapsed = float(mx[1])  # the slowest rank's wall time
     rays_all = float(tot[0])
     if rank != 0:
         if world > 1:

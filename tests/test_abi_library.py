@@ -1,0 +1,72 @@
+"""The C-ABI library builds, loads on a machine without a GPU, and exports what include/rt_hip.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rt_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def library():
+    from raytrace_amd import _lib
+    path = _lib.lib_path()
+    if not os.path.exists(path):
+        pytest.fail(f"{path} is missing: run `python __graft_entry__.py` (build()) first")
+    return _lib.open_library()
+
+
+def test_header_declares_the_entry_points():
+    names = declared_functions()
+    for must in ("rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
+                 "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info"):
+        assert must in names, must
+
+
+def test_library_exports_every_declared_symbol():
+    lib = library()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} is declared in rt_hip.h but not exported"
+
+
+def test_struct_sizes_match_the_header():
+    """ctypes mirrors against the sizes the C compiler computes for the header's structs."""
+    import subprocess, sys, tempfile
+    from raytrace_amd import abi
+    pairs = [("rt_sphere", abi.Sphere), ("rt_quad", abi.Quad), ("rt_cylinder", abi.Cylinder), ("rt_triangle", abi.Triangle),
+             ("rt_face", abi.Face), ("rt_mesh", abi.Mesh), ("rt_transformed", abi.Transformed), ("rt_image", abi.Image),
+             ("rt_texture", abi.Texture), ("rt_material", abi.Material), ("rt_light", abi.Light), ("rt_node", abi.Node),
+             ("rt_scene_desc", abi.SceneDesc), ("rt_camera_desc", abi.CameraDesc), ("rt_render_opts", abi.RenderOpts),
+             ("rt_stats", abi.Stats), ("rt_hit", abi.Hit), ("rt_bvh_info", abi.BvhInfo)]
+    src = '#include <stdio.h>\n#include "rt_hip.h"\nint main(void){' + "".join(
+        f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        cfile, exe = os.path.join(d, "s.c"), os.path.join(d, "s")
+        open(cfile, "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    for (cname, ct), size in zip(pairs, sizes):
+        assert C.sizeof(ct) == size, f"{cname}: header {size} bytes, ctypes mirror {C.sizeof(ct)}"
+
+
+def test_product_path_fails_loudly_without_a_gpu():
+    """No CPU fallback: on a machine without a GPU the library refuses to initialise and says why."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = library()
+    ids = (C.c_int * 1)(0)
+    rc = lib.rt_init(ids, 1)
+    assert rc != 0
+    assert len(lib.rt_last_error()) > 0
+    from raytrace_amd import phys, scenes
+    with pytest.raises(Exception):
+        phys.Render(scenes.scan(level=1, dx=16, dy=16, spp=1, tex_size=8))

@@ -1,0 +1,97 @@
+"""Host-side mirror of the reference's scene API: Validate rules, flattening into the C description,
+option plumbing and the band rule.  No GPU and no library calls."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytrace_amd import abi, phys, scenes, shard
+
+
+def test_render_options_validate_matches_the_reference_rules():  # render.go:81-98
+    ok = phys.RenderOptions(Seed=0, RaysPerPixel=1, MaxRayDepth=1, Dx=1, Dy=1)
+    ok.Validate()
+    for field, bad in (("Seed", -1), ("RaysPerPixel", 0), ("MaxRayDepth", 0), ("Dx", 0), ("Dy", -3)):
+        o = phys.RenderOptions(Seed=0, RaysPerPixel=1, MaxRayDepth=1, Dx=1, Dy=1)
+        setattr(o, field, bad)
+        with pytest.raises(ValueError, match=field):
+            o.Validate()
+
+
+def test_shape_validate_rejects_what_the_reference_rejects():
+    with pytest.raises(ValueError):
+        phys.Sphere((0, 0, 0), 0.0).Validate()  # shape_sphere.go:253-269: radius must be positive
+    with pytest.raises(ValueError):
+        phys.Quad((0, 0, 0), (0, 0, 2), 1.0, 1.0).Validate()  # normal must be a unit vector, shape_quad.go:22-36
+    with pytest.raises(ValueError):
+        phys.Triangle((0, 0, 0), (1, 0, 0), (2, 0, 0)).Validate()  # collinear, shape_triangle.go:52-86
+    with pytest.raises(ValueError):
+        phys.Cylinder((0, 0, 0), (0, 0, 0), 1.0, 1.0).Validate()  # zero direction, shape_cylinder.go:22-36
+    phys.Triangle((0, 0, 0), (1, 0, 0), (0, 1, 0)).Validate()
+
+
+def test_scene_validate_needs_a_camera_and_unique_node_names():  # scene.go:36-79
+    s = scenes.cornell(dx=8, dy=8, spp=1)
+    s.Validate()
+    cams, s.Camera = s.Camera, []
+    with pytest.raises(ValueError, match="no cameras"):
+        s.Validate()
+    s.Camera = cams
+    s.Node.append(phys.Node(s.Node[0].Name, s.Node[0].Shape, s.Node[0].Material))
+    with pytest.raises(ValueError, match="duplicate node name"):
+        s.Validate()
+
+
+def test_flatten_counts_and_sharing():
+    s = scenes.cornell(dx=8, dy=8, spp=1)
+    f = phys.FlatScene(s)
+    d = f.desc
+    assert d.n_nodes == len(s.Node)
+    assert d.n_lights == len(s.Light)
+    kinds = [d.nodes[i].shape_kind for i in range(d.n_nodes)]
+    assert kinds.count(abi.SHAPE_QUAD) == d.n_quads
+    assert kinds.count(abi.SHAPE_SPHERE) == d.n_spheres
+    # one material object used by several nodes is uploaded once
+    mats = {id(n.Material) for n in s.Node}
+    assert d.n_materials == len(mats)
+    for i in range(d.n_nodes):
+        assert 0 <= d.nodes[i].material < d.n_materials
+
+
+def test_flatten_mesh_faces_layout():
+    s = scenes.scan(level=1, dx=8, dy=8, spp=1, tex_size=8)
+    f = phys.FlatScene(s)
+    d = f.desc
+    assert d.n_meshes == 1 and d.n_faces == 80  # icosphere level 1
+    assert C.sizeof(abi.Face) == 15 * 8  # three (x, y, z, u, v) vertices, the reference's Face (shape_mesh.go:12-16)
+    assert f.faces.shape == (80, 3, 5) and f.faces.dtype == np.float64
+    assert d.meshes[0].first_face == 0 and d.meshes[0].n_faces == 80
+
+
+def test_render_opts_plumbing():
+    o = phys.RenderOptions(Seed=7, RaysPerPixel=9, MaxRayDepth=3, Dx=20, Dy=10)
+    ro = phys.render_opts(o, abi.MODE_REFERENCE, band_rank=1, band_world=2, sample_begin=4, sample_count=5)
+    assert (ro.seed, ro.rays_per_pixel, ro.max_ray_depth, ro.dx, ro.dy) == (7, 9, 3, 20, 10)
+    assert (ro.mode, ro.band_rank, ro.band_world, ro.sample_begin, ro.sample_count) == (abi.MODE_REFERENCE, 1, 2, 4, 5)
+
+
+def test_camera_desc_kinds():
+    for s, kind in ((scenes.cornell(dx=8, dy=8, spp=1), abi.CAM_PINHOLE), (scenes.scan(level=1, dx=8, dy=8, spp=1, tex_size=8), abi.CAM_ORTHOGRAPHIC),
+                    (scenes.teapot(dx=8, dy=8, spp=1), abi.CAM_FOCUSABLE)):
+        assert phys.camera_desc(s.Camera[0]).kind == kind
+
+
+def test_scene_generators_are_deterministic():
+    a = phys.FlatScene(scenes.scan(level=2, dx=8, dy=8, spp=1, tex_size=8)).faces
+    b = phys.FlatScene(scenes.scan(level=2, dx=8, dy=8, spp=1, tex_size=8)).faces
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dy,world", [(1, 1), (16, 2), (100, 3), (2160, 8), (17, 4)])
+def test_band_rows_partition_the_frame(dy, world):
+    seen = np.concatenate([shard.band_rows(dy, r, world) for r in range(world)])
+    assert sorted(seen.tolist()) == list(range(dy))
+    for r in range(world):
+        rows = shard.band_rows(dy, r, world)
+        assert all(shard.owns_row(int(y), r, world) for y in rows)
+        assert all((int(y) // shard.BAND_ROWS) % world == r for y in rows)
