@@ -344,6 +344,91 @@ def material(dx=2048, dy=2048, spp=4096, depth=5, seed=0, tex_size=(564, 568)) -
                       RenderOptions=phys.RenderOptions(seed, spp, depth, dx, dy))
 
 
+def charuco_board_image(size: int = 1772, squares: int = 7, seed: int = 4242) -> np.ndarray:
+    """Stand-in for example/charuco/asset/Square150MM.png (1772x1772): a chessboard whose white squares
+    carry a random 6x6 bit marker, RGBA8."""
+    rng = np.random.default_rng(seed)
+    img = np.full((size, size, 4), 255, dtype=np.uint8)
+    sq = size // squares
+    for r in range(squares):
+        for c in range(squares):
+            y0, x0 = r * sq, c * sq
+            if (r + c) % 2 == 0:
+                img[y0:y0 + sq, x0:x0 + sq, :3] = 0
+            else:
+                cell = sq // 8
+                bits = rng.integers(0, 2, size=(6, 6))
+                for i in range(6):
+                    for j in range(6):
+                        if bits[i, j]:
+                            img[y0 + (i + 1) * cell:y0 + (i + 2) * cell, x0 + (j + 1) * cell:x0 + (j + 2) * cell, :3] = 0
+    return img
+
+
+def led_ring_positions(n: int = 257, outer_mm: float = 43.4) -> np.ndarray:
+    """Stand-in for the LED table of example/gem/led.go (PAL257: 257 emitters on 8 concentric rings, outer
+    radius 43.4 mm): one centre LED and rings of 8, 16, ... LEDs whose counts add up to n."""
+    counts = [8, 16, 24, 32, 40, 44, 44, 48]
+    assert 1 + sum(counts) == n
+    pts = [(0.0, 0.0)]
+    for k, c in enumerate(counts, start=1):
+        rad = outer_mm * k / len(counts)
+        for i in range(c):
+            a = 2.0 * math.pi * (i + 0.5 * (k % 2)) / c
+            pts.append((rad * math.cos(a), rad * math.sin(a)))
+    return np.array(pts)
+
+
+def charuco(dx=1440, dy=1080, spp=16, depth=6, seed=0, frame=0, frames_per_orbit=240, leds=False) -> phys.Scene:
+    """example/charuco/main.go:36-289: emitter spheres on the corners of a 150 mm box, three axis cylinders,
+    twelve cylinder rods along the box edges, a 150 mm quad with an image texture (default nearest
+    sampling), CalibratedCamera{IntrinsicsFireflyDLGeneric6mm} on an orbit of radius 400 mm at height 320 mm
+    with VUp = -Z, one point light.  frame selects the orbit position (theta = 2 pi frame / frames_per_orbit).
+    leds=True adds the light-loop stress case: a Lambertian ground quad under 257 point lights
+    (I = 0.3 / 257 each) placed 100 mm above it on the rings of led_ring_positions()."""
+    W = H = D = 150.0 * MM
+    colormap0 = (0.5, 0.5, 0.5)
+    P = (203.0 / 255.0, 136.0 / 255.0, 206.0 / 255.0)
+    cx_, cy_, cz_ = (1.0, 0.0, 157.0 / 255.0), (157.0 / 255.0, 1.0, 0.0), (0.0, 57.0 / 255.0, 1.0)
+
+    def ball(name, col, x, y, z):  # main.go:342-350
+        return phys.Node(name, phys.Sphere((x, y, z), 4.0 * MM), phys.Emitter(phys.TextureUniform(col)))
+
+    def rod(name, col, o, d, h):
+        return phys.Node(name, phys.Cylinder(o, d, 1.0 * MM, h), phys.Emitter(phys.TextureUniform(col)))
+
+    nodes = [ball("Origin", colormap0, 0.0, 0.0, 0.0)]
+    corners = [(-W / 2, -H / 2), (W / 2, -H / 2), (W / 2, H / 2), (-W / 2, H / 2)]
+    for i, (x, y) in enumerate(corners):
+        nodes.append(ball(f"P{i + 1}", P, x, y, D))
+    for i, (x, y) in enumerate(corners):
+        nodes.append(ball(f"P{i + 5}", P, x, y, 0.0))
+    nodes += PropAxes((0.0, 0.0, 0.0), 0.5 * MM, 20.0 * MM, "")
+    X, Y, Z = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
+    nodes += [
+        rod("AxisX1Top", cx_, (-W / 2, -H / 2, D), X, W), rod("AxisX2Top", cx_, (-W / 2, H / 2, D), X, W),
+        rod("AxisY1Top", cy_, (-W / 2, -H / 2, D), Y, H), rod("AxisY2Top", cy_, (W / 2, -H / 2, D), Y, H),
+        rod("AxisX1Bottom", cx_, (-W / 2, -H / 2, 0.0), X, W), rod("AxisX2Bottom", cx_, (-W / 2, H / 2, 0.0), X, W),
+        rod("AxisZ1Top", cz_, (-W / 2, H / 2, 0.0), Z, D), rod("AxisZ2Top", cz_, (W / 2, H / 2, 0.0), Z, D),
+        rod("AxisZ1Bottom", cz_, (-W / 2, -H / 2, 0.0), Z, D), rod("AxisZ2Bottom", cz_, (W / 2, -H / 2, 0.0), Z, D),
+        rod("AxisY1Bottom", cy_, (-W / 2, -H / 2, 0.0), Y, H), rod("AxisY2Bottom", cy_, (W / 2, -H / 2, 0.0), Y, H),
+        phys.Node("CharucoSquare150MM", phys.Quad((0.0, 0.0, 0.0), Z, 150.0 * MM, 150.0 * MM),
+                  phys.Emitter(phys.TextureImage(charuco_board_image(), "", ""))),
+    ]
+    lights = [phys.PointLight((500.0 * MM, 500.0 * MM, 500.0 * MM), (0.3, 0.3, 0.3))]
+    if leds:
+        nodes.append(phys.Node("LedGround", phys.Quad((0.0, 0.0, -2.0 * MM), Z, 400.0 * MM, 400.0 * MM),
+                               phys.Lambertian(phys.TextureUniform((0.8, 0.8, 0.8)))))
+        each = 0.3 / 257.0
+        lights = [phys.PointLight((x * MM, y * MM, 100.0 * MM), (each, each, each)) for x, y in led_ring_positions()]
+    theta = 2.0 * math.pi * (frame % frames_per_orbit) / frames_per_orbit
+    cam = phys.CalibratedCamera(
+        Intrinsics=phys.IntrinsicsFireflyDLGeneric6mm,
+        Extrinsics=phys.CameraExtrinsics(LookFrom=(400.0 * MM * math.cos(theta), 400.0 * MM * math.sin(theta), 320.0 * MM),
+                                         LookAt=(0.0, 0.0, D / 2), VUp=(0.0, 0.0, -1.0)))
+    return phys.Scene(Camera=[cam], Node=nodes, Light=lights, RenderOptions=phys.RenderOptions(seed, spp, depth, dx, dy))
+
+
 def random_faces(n: int, seed: int = 1) -> np.ndarray:
     """The reference's BVH micro-benchmark input (shape_bvh_test.go:60-98): n faces with
     vertices uniform in [-50,50]^3 and uniform UVs (seeded here; the reference uses the

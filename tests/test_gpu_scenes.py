@@ -1,0 +1,162 @@
+"""GPU parity, second file: the charuco / LED configuration, image-texture sampling modes, cancellation,
+converged images and edge-case frames.  Same bars as test_gpu_parity.py."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from raytrace_amd import abi, phys, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    binding.load()
+    return binding
+
+
+def _pair(ob, sc, mode=abi.MODE_REFERENCE):
+    with phys.DeviceScene(sc) as dev, ob.OracleScene(sc) as orc:
+        art = dev.render(sc.Camera[0], sc.RenderOptions, mode)
+        img, st, _, _ = orc.render(sc.Camera[0], sc.RenderOptions)
+    return art, img, st
+
+
+@pytest.mark.parametrize("frame", [0, 37])
+def test_charuco_calibrated_camera_frames(ob, frame):
+    # emitter-only scene seen through the distorting calibrated camera: no stochastic material, so the
+    # images may differ only by one quantisation level
+    sc = scenes.charuco(dx=360, dy=270, spp=2, frame=frame)
+    for mode in (abi.MODE_REFERENCE, abi.MODE_FAST):
+        art, img, st = _pair(ob, sc, mode)
+        assert art.Stats.TotalRays == st.total_rays
+        assert art.Stats.RaysLeftScene == st.rays_left_scene
+        diff = np.abs(art.Image.astype(int) - img.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    assert (img[..., :3].max(axis=2) > 0).mean() > 0.05  # the board and rods are in view
+
+
+def test_charuco_with_257_point_lights(ob):
+    sc = scenes.charuco(dx=160, dy=120, spp=2, leds=True)
+    assert len(sc.Light) == 257
+    art, img, st = _pair(ob, sc)
+    assert abs(art.Stats.TotalRays - st.total_rays) <= 1e-3 * st.total_rays
+    assert abs(art.Stats.ShadowRays - st.shadow_rays) <= 1e-3 * st.shadow_rays
+    assert st.shadow_rays >= 257 * 1000
+    diff = np.abs(art.Image[..., :3].astype(int) - img[..., :3].astype(int))
+    assert (diff > 1).mean() < 5e-3, ((diff > 1).mean(), diff.max())
+
+
+@pytest.mark.parametrize("interp", ["", "nearest", "bilinear"])
+@pytest.mark.parametrize("wrap", ["", "repeat", "clamp", "mirror"])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_image_texture_modes_match_oracle(ob, interp, wrap, dtype):
+    # TextureImage.At (texture_image.go:60-151) through an Emitter quad whose uv runs far outside [0, 1]
+    rng = np.random.default_rng(5)
+    if dtype == np.uint8:
+        tex = rng.integers(0, 256, size=(13, 17, 4), dtype=np.uint8)
+    else:
+        tex = rng.integers(0, 65536, size=(13, 17, 4)).astype(np.uint16)
+        tex[..., :3] = np.minimum(tex[..., :3], tex[..., 3:4])  # alpha-premultiplied, as color.Color.RGBA() reports
+    quad = phys.Node("q", phys.Quad((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 4.0, 4.0), phys.Emitter(phys.TextureImage(tex, interp, wrap)))
+    cam = phys.OrthographicCamera(LookFrom=(0.0, 0.0, 10.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 1.0, 0.0), FOVHeight=4.2, FOVWidth=4.2)
+    sc = phys.Scene(Camera=[cam], Node=[quad], RenderOptions=phys.RenderOptions(0, 1, 2, 96, 96))
+    art, img, st = _pair(ob, sc)
+    assert np.abs(art.Image.astype(int) - img.astype(int)).max() <= 1
+    assert img[..., :3].std() > 5
+
+
+def test_cancel_returns_cancelled_and_scene_stays_usable():
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    sc = scenes.scan(level=6, dx=1920, dy=1080, spp=4096, tex_size=256, lit=True)  # minutes of work if not cancelled
+    with phys.DeviceScene(sc) as dev:
+        cd = phys.camera_desc(sc.Camera[0])
+        ro = phys.render_opts(sc.RenderOptions, abi.MODE_FAST)
+        img = np.zeros((1080, 1920, 4), dtype=np.uint8)
+        result = {}
+
+        def run():
+            result["rc"] = lib.rt_render(dev.handle, C.byref(cd), C.byref(ro), img.ctypes.data_as(C.POINTER(C.c_uint8)), 1920 * 4, None)
+            result["msg"] = lib.rt_last_error()
+
+        th = threading.Thread(target=run)
+        t0 = time.time()
+        th.start()
+        time.sleep(0.5)
+        lib.rt_cancel(dev.handle)
+        th.join(60)
+        assert not th.is_alive()
+        assert result["rc"] == abi.RT_ERR_CANCELLED, result
+        assert b"cancel" in result["msg"]
+        assert time.time() - t0 < 30
+        # the handle renders normally afterwards (render.go:229-233: cancellation only abandons that render)
+        small = phys.RenderOptions(0, 1, 2, 64, 36)
+        art = dev.render(sc.Camera[0], small, abi.MODE_FAST)
+        assert art.Stats.TotalRays >= 64 * 36
+
+
+def test_converged_image_rmse_against_oracle(ob):
+    # different seeds on the two sides: agreement is statistical, as it would be against the Go renderer
+    sc = scenes.cornell(32, 32, 2048, 5, seed=1)
+    with phys.DeviceScene(sc) as dev:
+        art = dev.render(sc.Camera[0], sc.RenderOptions, abi.MODE_FAST)
+    sc2 = scenes.cornell(32, 32, 2048, 5, seed=2)
+    with ob.OracleScene(sc2) as orc:
+        img, st, _, _ = orc.render(sc2.Camera[0], sc2.RenderOptions)
+    a = art.Image[..., :3].astype(float) / 255.0
+    b = img[..., :3].astype(float) / 255.0
+    rmse = float(np.sqrt(np.mean((a - b) ** 2)))
+    assert rmse < 0.02, rmse  # north-star tolerance: RMSE < 2e-2 between converged images
+    assert abs(a.mean() - b.mean()) < 0.005
+
+
+@pytest.mark.parametrize("dx,dy,spp", [(1, 1, 1), (1, 37, 3), (67, 1, 2), (65, 17, 1), (8, 8, 130)])
+def test_ragged_frames_and_sample_counts(ob, dx, dy, spp):
+    # frames that do not fill 8x8 tiles / 64x64 groups / 16-row bands, and sample counts that split into passes
+    sc = scenes.scan(level=3, dx=dx, dy=dy, spp=spp, tex_size=32)
+    for mode in (abi.MODE_REFERENCE, abi.MODE_FAST):
+        art, img, st = _pair(ob, sc, mode)
+        assert art.Stats.TotalRays == st.total_rays == dx * dy * spp
+        assert art.Stats.RaysLeftScene == st.rays_left_scene
+        assert np.abs(art.Image.astype(int) - img.astype(int)).max() <= 1
+
+
+def test_empty_scene_and_all_miss(ob):
+    cam = phys.OrthographicCamera(LookFrom=(0.0, 0.0, 10.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 1.0, 0.0), FOVHeight=1.0, FOVWidth=1.0)
+    sc = phys.Scene(Camera=[cam], Node=[], RenderOptions=phys.RenderOptions(0, 2, 3, 40, 24))
+    with phys.DeviceScene(sc) as dev:
+        art = dev.render(cam, sc.RenderOptions, abi.MODE_FAST)
+    assert art.Stats.TotalRays == art.Stats.RaysLeftScene == 40 * 24 * 2
+    assert not art.Image[..., :3].any() and (art.Image[..., 3] == 255).all()  # black, opaque (render.go:170-172, 218-224)
+    o = np.zeros((0, 3)); d = np.zeros((0, 3))
+    with phys.DeviceScene(sc) as dev:
+        assert len(dev.intersect(o, d)) == 0
+
+
+def test_frozen_oracle_fixtures_on_gpu():
+    """The committed fixtures (tests/golden/oracle_*.npz, generated from the oracle) against the GPU alone."""
+    import importlib.util
+    import os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(g, "make_oracle_fixtures.py"))
+    hits = np.load(os.path.join(g, "oracle_hits.npz"))
+    faces = scenes.random_faces(2000, seed=11)
+    sc = phys.Scene(Camera=[], Node=[phys.Node("m", phys.NewMesh(faces), phys.DebugNormal()),
+                                    phys.Node("s", phys.Sphere((10.0, -20.0, 5.0), 30.0), phys.DebugUV())])
+    with phys.DeviceScene(sc) as dev:
+        h = dev.intersect(hits["o"], hits["d"], 1e-3, 1.7976931348623157e308, abi.MODE_REFERENCE)
+    assert np.array_equal(h["node"], hits["node"])
+    m = hits["node"] >= 0
+    for k in ("prim", "t", "at", "normal", "uv"):
+        assert np.array_equal(h[k][m], hits[k][m]), k
+    imgs = np.load(os.path.join(g, "oracle_images.npz"))
+    for name, scn in (("scan", scenes.scan(level=3, dx=48, dy=32, spp=2, tex_size=32)), ("charuco", scenes.charuco(dx=48, dy=36, spp=1))):
+        with phys.DeviceScene(scn) as dev:
+            art = dev.render(scn.Camera[0], scn.RenderOptions, abi.MODE_REFERENCE)
+        assert np.abs(art.Image.astype(int) - imgs[name].astype(int)).max() <= 1, name
+        assert art.Stats.TotalRays == int(imgs[name + "_stats"][0])

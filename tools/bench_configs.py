@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE configurations (stochastic materials: shade / light-loop / scattered-ray
+generations), fast mode, one GPU.  usage: bench_configs.py [name ...]"""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from raytrace_amd import abi, phys, scenes
+
+CONFIGS = {
+    "cornell": lambda: scenes.cornell(dx=256, dy=256, spp=64),
+    "teapot": lambda: scenes.teapot(dx=1920, dy=1080, spp=32),
+    "material": lambda: scenes.material(dx=1024, dy=1024, spp=32),
+    "scan_lit": lambda: scenes.scan(level=7, dx=1920, dy=1080, spp=16, tex_size=1024, lit=True),
+}
+names = sys.argv[1:] or list(CONFIGS)
+for name in names:
+    sc = CONFIGS[name]()
+    with phys.DeviceScene(sc) as dev:
+        dev.render(sc.Camera[0], sc.RenderOptions)  # warm-up: queues allocated
+        t0 = time.perf_counter()
+        art = dev.render(sc.Camera[0], sc.RenderOptions)
+        dt = time.perf_counter() - t0
+    st = art.Stats
+    print(f"{name:9s} {sc.RenderOptions.Dx}x{sc.RenderOptions.Dy}@{sc.RenderOptions.RaysPerPixel}: {st.TotalRays/dt/1e6:8.1f} Mrays/s "
+          f"({st.TotalRays/1e6:.1f} M rays + {st.ShadowRays/1e6:.1f} M shadow rays in {dt*1e3:.1f} ms; traversal launches {st.TraverseLaunches}, "
+          f"{st.TraverseSeconds*1e3:.1f} ms inside them)", flush=True)
