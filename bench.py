@@ -7,7 +7,7 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on): the scan s
 pixel, fast mode.  One "step" renders `--spp-step` consecutive sample indices of every pixel of
 the frame (default 64, so 16 steps are the whole 1024-spp frame); the rows of the frame are cut
 into 16-row bands dealt round-robin to the ranks, every rank keeps the whole scene in its own
-HBM, and the per-rank films are summed onto rank 0 with one RCCL reduce after the last step.
+HBM, and the per-rank films are gathered onto rank 0 with one RCCL gather after the last step.
 
 Prints ONE JSON line on rank 0.  `value` is TotalRays (the reference's RenderStats counter,
 render.go:143) of all ranks divided by the slowest rank's wall time for the K timed steps.
@@ -38,6 +38,8 @@ def parse():
     p.add_argument("--tex", type=int, default=4096)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
+    p.add_argument("--emulate-world", type=int, default=0,
+                   help="single process renders only the row bands that rank 0 of this many ranks would own (scaling rehearsal)")
     p.add_argument("--check", action="store_true", help="compare a crop of the GPU image with the oracle")
     return p.parse_args()
 
@@ -114,7 +116,7 @@ def main():
     def step(k):
         s0 = (k * a.spp_step) % o.RaysPerPixel
         cnt = min(a.spp_step, o.RaysPerPixel - s0)
-        ro = phys.render_opts(o, abi.MODE_FAST, rank, world, stream, s0, cnt)
+        ro = phys.render_opts(o, abi.MODE_FAST, rank, a.emulate_world or world, stream, s0, cnt)
         st = abi.Stats()
         _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
         return st
@@ -173,7 +175,7 @@ def main():
                         f"Emitter + {a.tex}x{a.tex} bilinear image texture, orthographic camera, {o.Dx}x{o.Dy} @ {o.RaysPerPixel} spp, "
                         f"MaxRayDepth {o.MaxRayDepth}; one step = {a.spp_step} sample indices of every pixel",
             "mode": "fast (float32 conservative box culling, float64 face intersection)",
-            "parallelism": f"16-row bands round-robin over {world} GPU(s), scene replicated, one RCCL reduce of the film",
+            "parallelism": f"16-row bands round-robin over {world} GPU(s), scene replicated, one RCCL gather of each GPU's rows",
             "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.max_depth), "bvh_build_s": info.build_seconds,
             "scene_upload_s": upload_s,
             "rays_per_step_all_gpus": rays_all / max(a.steps, 1),

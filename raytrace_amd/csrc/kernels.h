@@ -20,6 +20,13 @@ struct PassDesc {
     int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group
     int64_t n_pixels;               // tiles * 64 = pixels (threads) of this pass
     uint32_t seed_lo, seed_hi;
+    // Work order of the primary launch.  Tiles belong to 8 queues (group of 8x8 tiles g -> queue g % 8).  With
+    // `order` set, queue k hands out order[queue_off[k] + i], i < queue_len[k] (tile numbers, costliest
+    // first); without it, its tiles in ascending order.  With `cost` set, every work item adds the clock ticks
+    // it took to cost[tile].
+    const int32_t* order;
+    uint32_t* cost;
+    uint32_t queue_off[8], queue_len[8];
 };
 
 struct Queues {

@@ -324,8 +324,13 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
                 const uint32_t owner = (xcd + k) & 7;
                 const uint32_t item = atomicAdd(&q.counters->tile_cursor[owner], 1u);
                 const uint32_t idx = item / n_chunks;
-                const long long cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
-                if (cand < n_tiles) {
+                long long cand = -1;
+                if (pass.order) {
+                    if (idx < pass.queue_len[owner]) cand = pass.order[pass.queue_off[owner] + idx];
+                } else {
+                    cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
+                }
+                if (cand >= 0 && cand < n_tiles) {
                     v = cand;
                     chunk = item - idx * n_chunks;
                 }
@@ -333,6 +338,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
         }
         v = __shfl(v, 0, 64);
         if (v < 0) break;
+        const long long t_start = pass.cost ? clock64() : 0;
         chunk = __shfl(chunk, 0, 64);
         const int k_begin = (int)chunk * pass.chunk;
         const int k_end = k_begin + pass.chunk < pass.sample_count ? k_begin + pass.chunk : pass.sample_count;
@@ -343,7 +349,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
         const int ly = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8 + (p >> 3);
         const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
         const bool live = lx < pass.dx && ly < pass.local_rows && row < pass.dy;
-        if (__ballot(live) == 0) continue;
+        if (__ballot(live) == 0) continue;  // a tile outside the frame: cost stays 0
         const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
         const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
         V3 acc = mk(0, 0, 0);
@@ -388,6 +394,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
                 film_add(film, pixel, acc);
             }
         }
+        if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
     wave_tally(q.counters, n_total, n_left, 0);
 }

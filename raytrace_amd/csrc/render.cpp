@@ -8,9 +8,12 @@
 // leaves k_primary and is rendered without a single host synchronisation per pass.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "host_common.h"
 
@@ -27,6 +30,14 @@ struct WorkBuffers {
     size_t rgba_bytes = 0;
     double* film = nullptr;
     size_t film_doubles = 0;
+    // Cost-ordered schedule of the primary launch, measured by a short pilot pass and kept while the
+    // camera and the frame stay the same (animation frames and progressive passes re-use it).
+    uint32_t* tile_cost = nullptr;
+    int32_t* tile_order = nullptr;
+    size_t order_tiles = 0;
+    std::string order_key;
+    bool order_valid = false;
+    uint32_t queue_off[8] = {}, queue_len[8] = {};
 };
 
 void destroy_work(WorkBuffers* w) {
@@ -34,6 +45,8 @@ void destroy_work(WorkBuffers* w) {
     if (w->pool_base) (void)hipFree(w->pool_base);
     if (w->rgba) (void)hipFree(w->rgba);
     if (w->film) (void)hipFree(w->film);
+    if (w->tile_cost) (void)hipFree(w->tile_cost);
+    if (w->tile_order) (void)hipFree(w->tile_order);
     delete w;
 }
 
@@ -149,6 +162,37 @@ struct EventPool {  // HIP-event timing of the traversal launches, on the stream
     }
 };
 
+// Turns the pilot pass's per-tile costs into the work order of the 8 queues.
+int build_tile_order(WorkBuffers& w, int64_t tiles_total, hipStream_t stream) {
+    std::vector<uint32_t> cost((size_t)tiles_total);
+    HIP_TRY(hipMemcpyAsync(cost.data(), w.tile_cost, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<int32_t> order;
+    order.reserve((size_t)tiles_total);
+    double sum = 0;
+    size_t busy = 0;
+    for (uint32_t c : cost)
+        if (c) { sum += c; busy++; }
+    const double mean = busy ? sum / (double)busy : 1.0;
+    // three classes only: the few tiles that cost several times the mean go first (they would otherwise end the
+    // launch with most of the chip idle); everything else keeps its spatial order and with it its L2 locality
+    auto klass = [&](int32_t t) {
+        const double c = (double)cost[(size_t)t];
+        return c >= 4.0 * mean ? 2 : (c >= 2.0 * mean ? 1 : 0);
+    };
+    for (int k = 0; k < 8; k++) {
+        const size_t begin = order.size();
+        for (int64_t g = k; g * 64 < tiles_total; g += 8)
+            for (int t = 0; t < 64 && g * 64 + t < tiles_total; t++) order.push_back((int32_t)(g * 64 + t));
+        std::stable_sort(order.begin() + begin, order.end(), [&](int32_t a, int32_t b) { return klass(a) > klass(b); });
+        w.queue_off[k] = (uint32_t)begin;
+        w.queue_len[k] = (uint32_t)(order.size() - begin);
+    }
+    HIP_TRY(hipMemcpyAsync(w.tile_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // `order` goes out of scope
+    return RT_OK;
+}
+
 }  // namespace
 
 int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba) {
@@ -238,13 +282,38 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         return RT_OK;
     };
 
+    // Cost-ordered schedule: worth a pilot pass when the frame has many tiles and more than a few samples.
+    const std::string order_key = std::string(reinterpret_cast<const char*>(camera), sizeof(*camera)) + "|" + std::to_string(o->dx) + "x" +
+                                  std::to_string(o->dy) + "|" + std::to_string(rank) + "/" + std::to_string(world) + "|" + std::to_string(o->mode);
+    const bool want_order = tiles_total >= 2048 && std::getenv("RT_NO_TILE_ORDER") == nullptr;
+    if (want_order && (w.order_tiles != (size_t)tiles_total || !w.tile_cost)) {
+        if (w.tile_cost) (void)hipFree(w.tile_cost);
+        if (w.tile_order) (void)hipFree(w.tile_order);
+        w.tile_cost = nullptr;
+        w.tile_order = nullptr;
+        w.order_valid = false;
+        w.order_tiles = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.tile_cost), (size_t)tiles_total * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.tile_order), (size_t)tiles_total * sizeof(int32_t)));
+        w.order_tiles = (size_t)tiles_total;
+    }
+    if (w.order_valid && w.order_key != order_key) w.order_valid = false;
+    constexpr int kPilotSamples = 2;
+    // samples per pass: enough work per launch (about a 4K frame x 64 samples) that its tail stays small
+    int pass_samples = (int)std::min<int64_t>(1024, 64 * std::max<int64_t>(1, 130560 / std::max<int64_t>(tiles_total, 1)));
+    if (const char* e = getenv("RT_PASS_SAMPLES")) pass_samples = std::max(1, atoi(e));
     int chunk_override = 0;  // RT_CHUNK: tuning knob for the samples per work item
     if (const char* e = getenv("RT_CHUNK")) chunk_override = std::max(1, atoi(e));
     for (int s0 = s_first; s0 < s_end;) {
         // a pass covers all tiles for a run of samples when that fits, else a run of tiles for one sample
         int s_count = 1;
         if (tiles_total * 64 <= paths_per_launch)
-            s_count = (int)std::min<int64_t>(std::min(s_end - s0, 64), paths_per_launch / std::max<int64_t>(tiles_total * 64, 1));
+            s_count = (int)std::min<int64_t>(std::min(s_end - s0, pass_samples), paths_per_launch / std::max<int64_t>(tiles_total * 64, 1));
+        bool pilot = false;
+        if (want_order && !w.order_valid && tiles_total * 64 <= paths_per_launch && s_end - s0 > 2 * kPilotSamples) {
+            pilot = true;  // a short pass over the whole frame that records what every tile costs
+            s_count = std::min(s_count, kPilotSamples);
+        }
         const int64_t tiles_per_launch = std::max<int64_t>(1, paths_per_launch / (64 * (int64_t)s_count));
         for (int64_t t0 = 0; t0 < tiles_total; t0 += tiles_per_launch) {
             if (sc->cancel.load()) {
@@ -257,6 +326,11 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             pass.chunk = chunk_override > 0 ? chunk_override : (s_count >= 32 ? 4 : (s_count >= 2 ? 2 : 1));
             pass.tile_begin = t0;
             pass.n_pixels = nt * 64;
+            const bool whole = t0 == 0 && nt == tiles_total;
+            pass.order = (want_order && w.order_valid && whole) ? w.tile_order : nullptr;
+            pass.cost = (pilot && whole) ? w.tile_cost : nullptr;
+            for (int k = 0; k < 8; k++) { pass.queue_off[k] = w.queue_off[k]; pass.queue_len[k] = w.queue_len[k]; }
+            if (pass.cost) HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
             if (int rc = reset_cursors()) return rc;
             EventPair* ev = nullptr;
             HIP_TRY(events.next(&ev));
@@ -319,6 +393,11 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                 traverse_launches++;
                 n_traced = n;
             }
+        }
+        if (pilot) {
+            if (int rc = build_tile_order(w, tiles_total, stream)) return rc;
+            w.order_key = order_key;
+            w.order_valid = true;
         }
         s0 += s_count;
     }

@@ -1,7 +1,7 @@
-"""The N > 1 path on CPU: two processes (gloo), each renders its bands of the frame, one sum-reduce
-assembles the film on rank 0.  The CPU oracle stands in for the GPU renderer: it applies the same
+"""The N > 1 path on CPU: two processes (gloo), each renders its bands of the frame, one gather of
+the ranks' own rows assembles the film on rank 0.  The CPU oracle stands in for the GPU renderer: it applies the same
 band rule (band b -> rank b % world) when given band_rank / band_world, so the test pins the rule,
-the exactness of the reduce over disjoint rows and the counter combination that bench.py relies on."""
+the assembly of the frame from the ranks' rows and the counter combination that bench.py relies on."""
 import os
 import socket
 import sys
