@@ -448,6 +448,49 @@ class CalibratedCamera:  # camera_calibrated.go:32-90
         self.Extrinsics.Validate()
 
 
+@dataclass
+class AnimatedCamera:  # camera_animated.go:53-131
+    """A camera factory over normalized progress U.  The reference builds the concrete camera inside every
+    Cast call (a Go closure, camera_animated.go:70-74); since U is fixed for a frame the result is the same
+    camera for every ray, so it is built once here, before the camera crosses the C ABI."""
+    Build: Any          # callable u in [0, 1) -> camera
+    U: float = 0.0
+    Period: float = 0.0  # seconds per cycle; only WithTime / Advance use it
+
+    def _wrap01(self) -> float:
+        return self.U - math.floor(self.U)
+
+    def Resolve(self):
+        cam = self.Build(self._wrap01())
+        return cam.Resolve() if isinstance(cam, AnimatedCamera) else cam
+
+    def Validate(self):
+        if self.Build is None:
+            raise ValueError("AnimatedCamera.Build is nil")
+        cam = self.Build(self._wrap01())
+        if cam is None:
+            raise ValueError(f"AnimatedCamera.Build({self._wrap01():g}) returned nil Camera")
+        cam.Validate()
+
+    def WithU(self, u: float) -> "AnimatedCamera":
+        return AnimatedCamera(self.Build, float(u), self.Period)
+
+    def WithTime(self, t: float) -> "AnimatedCamera":
+        if self.Period == 0:
+            raise ValueError("AnimatedCamera.WithTime: Period is zero")
+        return self.WithU(t / self.Period)
+
+    def Advance(self, dt: float) -> "AnimatedCamera":
+        if self.Period == 0:
+            raise ValueError("AnimatedCamera.Advance: Period is zero")
+        return self.WithU(self.U + dt / self.Period)
+
+    def Frames(self, n: int):
+        if n <= 0 or self.Build is None:
+            return None
+        return [self.Build(i / n) for i in range(n)]
+
+
 # camera_calibrated_prefab.go:4-47
 IntrinsicsFireflyDLComputar16mm = CameraIntrinsics(1440, 1080, 4736.71083258, 4743.03975965, 770.21866744, 483.50827668,
                                                    -0.09261328, -1.43023836, -0.00215911, -0.00187976, 188.33757455)
@@ -721,6 +764,8 @@ class FlatScene:
 
 
 def camera_desc(cam) -> abi.CameraDesc:
+    if isinstance(cam, AnimatedCamera):
+        cam = cam.Resolve()
     d = abi.CameraDesc()
     if isinstance(cam, PinholeCamera):
         d.kind = abi.CAM_PINHOLE

@@ -95,3 +95,25 @@ def test_band_rows_partition_the_frame(dy, world):
         rows = shard.band_rows(dy, r, world)
         assert all(shard.owns_row(int(y), r, world) for y in rows)
         assert all((int(y) // shard.BAND_ROWS) % world == r for y in rows)
+
+
+def test_animated_camera_resolves_on_the_host():  # camera_animated.go:53-131
+    import math
+
+    def orbit(u):
+        a = 2 * math.pi * u
+        return phys.OrthographicCamera(LookFrom=(10 * math.cos(a), 10 * math.sin(a), 5.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0),
+                                       FOVHeight=4.0, FOVWidth=4.0)
+
+    ac = phys.AnimatedCamera(orbit, U=1.25, Period=8.0)
+    ac.Validate()
+    want = phys.camera_desc(orbit(0.25))
+    got = phys.camera_desc(ac)  # U wraps into [0, 1) at cast time
+    assert got.kind == abi.CAM_ORTHOGRAPHIC and tuple(got.look_from) == tuple(want.look_from)
+    assert phys.camera_desc(ac.WithTime(2.0)).look_from[0] == want.look_from[0]  # 2 s of an 8 s period = a quarter turn
+    assert abs(ac.Advance(4.0).U - 1.75) < 1e-15
+    assert len(ac.Frames(5)) == 5 and ac.Frames(0) is None
+    with pytest.raises(ValueError, match="Build is nil"):
+        phys.AnimatedCamera(None).Validate()
+    with pytest.raises(ValueError, match="Period is zero"):
+        phys.AnimatedCamera(orbit).WithTime(1.0)
