@@ -70,6 +70,6 @@ struct rt_scene {
 namespace rt {
 // The wavefront loop for one process's share of the image; adds radiance sums into film (device).
 int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats);
-// Scratch buffers owned by the scene for rt_render (film sums and the 8-bit image), grown on demand.
-int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba);
+// Scratch buffers owned by the scene for rt_render (film sums, the 8-bit image and its pinned host copy), grown on demand.
+int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host);
 }  // namespace rt

@@ -107,14 +107,29 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
     return hit;
 }
 
+// Fast mode only: can the ray reach node i's padded bounds within [tmin, tmax]?  fmin / fmax drop the NaN of
+// 0 * inf (origin on a slab plane of an axis the ray does not move along): that axis then does not constrain.
+RT_DEV bool node_box_reachable(const double* b, const Ray& r, V3 inv, double tmin, double tmax) {
+    const double x0 = (b[0] - r.o.x) * inv.x, x1 = (b[3] - r.o.x) * inv.x;
+    const double y0 = (b[1] - r.o.y) * inv.y, y1 = (b[4] - r.o.y) * inv.y;
+    const double z0 = (b[2] - r.o.z) * inv.z, z1 = (b[5] - r.o.z) * inv.z;
+    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmax(fmin(z0, z1), tmin));
+    const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmin(fmax(z0, z1), tmax));
+    return tn <= tf;
+}
+
 // The node loop of tracePath (render.go:155-169).  MESH_ONLY: the host has checked that every
 // node is a plain mesh, so the other shapes' code (and its registers) is left out.
 template <int MODE, bool MESH_ONLY = false>
 RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, LdsStack ls) {
     double min_dist = tmax;
     bool hit = false;
+    const bool cull = MODE == RT_MODE_FAST && !MESH_ONLY;  // a mesh clips the ray against its own root box
+    V3 inv = mk(0, 0, 0);
+    if (cull) inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     for (int i = 0; i < sc.n_nodes; i++) {
         const DNode nd = sc.nodes[i];
+        if (cull && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
         Col c;
         int prim;
         const bool got = MESH_ONLY ? mesh_node_collide<MODE>(sc, nd.index, r, tmin, min_dist, c, prim, cnt, ls)
@@ -137,9 +152,12 @@ template <int MODE>
 RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self_node, LdsStack ls) {
     const DNode self = sc.nodes[self_node];
     VisitCounts cnt{0, 0};
+    V3 inv = mk(0, 0, 0);
+    if (MODE == RT_MODE_FAST) inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     for (int i = 0; i < sc.n_nodes; i++) {
         const DNode nd = sc.nodes[i];
         if (nd.kind == self.kind && nd.index == self.index) continue;
+        if (MODE == RT_MODE_FAST && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, kEps, dist)) continue;
         if (MODE == RT_MODE_FAST && nd.kind == RT_SHAPE_MESH) {
             double t, u, v;
             int p;
@@ -623,13 +641,24 @@ static inline size_t stack_bytes(const DScene& sc, int mode) {
 // rounds over the 8 XCDs.
 template <typename K>
 static unsigned persistent_grid(K kernel, size_t lds) {
-    int device = 0, cus = 0, per_cu = 0;
+    // the answer depends only on (device, kernel, LDS bytes): keep the last one
+    static thread_local const void* cached_kernel = nullptr;
+    static thread_local int cached_device = -1;
+    static thread_local size_t cached_lds = 0;
+    static thread_local unsigned cached_grid = 0;
+    int device = 0;
     (void)hipGetDevice(&device);
+    if (reinterpret_cast<const void*>(kernel) == cached_kernel && device == cached_device && lds == cached_lds && cached_grid) return cached_grid;
+    int cus = 0, per_cu = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kTraceBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
     if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] primary: %d CUs x %d workgroups, %zu B LDS each\n", cus, per_cu, lds);
     const unsigned n = (unsigned)std::max(cus, 8) * (unsigned)per_cu;
-    return n & ~7u;
+    cached_kernel = reinterpret_cast<const void*>(kernel);
+    cached_device = device;
+    cached_lds = lds;
+    cached_grid = n & ~7u;
+    return cached_grid;
 }
 
 void launch_primary(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, int mode, bool mesh_only, double* film,

@@ -27,6 +27,7 @@ struct WorkBuffers {
     uint64_t pool_capacity = 0;
     void* pool_base = nullptr;
     uint8_t* rgba = nullptr;
+    uint8_t* rgba_host = nullptr;  // pinned staging copy of rgba: the caller's buffer is pageable
     size_t rgba_bytes = 0;
     double* film = nullptr;
     size_t film_doubles = 0;
@@ -44,6 +45,7 @@ void destroy_work(WorkBuffers* w) {
     if (!w) return;
     if (w->pool_base) (void)hipFree(w->pool_base);
     if (w->rgba) (void)hipFree(w->rgba);
+    if (w->rgba_host) (void)hipHostFree(w->rgba_host);
     if (w->film) (void)hipFree(w->film);
     if (w->tile_cost) (void)hipFree(w->tile_cost);
     if (w->tile_order) (void)hipFree(w->tile_order);
@@ -195,15 +197,18 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, hipStream_t stream) {
 
 }  // namespace
 
-int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba) {
+int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host) {
     if (int rc = ensure_work(sc)) return rc;
     WorkBuffers& w = *sc->work;
     const size_t px = (size_t)dx * dy;
     if (w.rgba_bytes < px * 4) {
         if (w.rgba) (void)hipFree(w.rgba);
+        if (w.rgba_host) (void)hipHostFree(w.rgba_host);
         w.rgba = nullptr;
+        w.rgba_host = nullptr;
         w.rgba_bytes = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.rgba), px * 4));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.rgba_host), px * 4, hipHostMallocDefault));
         w.rgba_bytes = px * 4;
     }
     if (w.film_doubles < px * 3) {
@@ -215,6 +220,7 @@ int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba) {
     }
     *film = w.film;
     *rgba = w.rgba;
+    *rgba_host = w.rgba_host;
     return RT_OK;
 }
 
@@ -310,7 +316,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         if (tiles_total * 64 <= paths_per_launch)
             s_count = (int)std::min<int64_t>(std::min(s_end - s0, pass_samples), paths_per_launch / std::max<int64_t>(tiles_total * 64, 1));
         bool pilot = false;
-        if (want_order && !w.order_valid && tiles_total * 64 <= paths_per_launch && s_end - s0 > 2 * kPilotSamples) {
+        if (want_order && !w.order_valid && tiles_total * 64 <= paths_per_launch && s_end - s0 >= 32) {  // fewer samples than that do not repay a pilot
             pilot = true;  // a short pass over the whole frame that records what every tile costs
             s_count = std::min(s_count, kPilotSamples);
         }

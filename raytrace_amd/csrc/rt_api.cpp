@@ -6,8 +6,10 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -160,6 +162,98 @@ int rt_init(const int* gpu_ids, int n) {
 
 void rt_shutdown(void) { g_initialized = false; }
 
+namespace {
+
+// Conservative world-space bounds of a shape for the fast mode's per-node culling.  They only have to
+// contain every point the shape's Collide can return, tolerances included (the triangle tests accept
+// barycentrics up to 1e-6 outside the triangle), so they are padded generously afterwards.
+struct Bounds {
+    double lo[3], hi[3];
+    void grow(V3 p) {
+        const double c[3] = {p.x, p.y, p.z};
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+    }
+};
+
+Bounds empty_bounds() {
+    const double inf = std::numeric_limits<double>::infinity();
+    return Bounds{{inf, inf, inf}, {-inf, -inf, -inf}};
+}
+
+Bounds shape_bounds(int kind, int index, const std::vector<DSphere>& spheres, const std::vector<DQuad>& quads,
+                    const std::vector<DCylinder>& cyls, const std::vector<DTri>& tris, const std::vector<DTransformed>& xforms,
+                    const std::vector<DMesh>& meshes, int depth = 0) {
+    Bounds b = empty_bounds();
+    const double inf = std::numeric_limits<double>::infinity();
+    const Bounds everything{{-inf, -inf, -inf}, {inf, inf, inf}};
+    switch (kind) {
+        case RT_SHAPE_SPHERE: {
+            const DSphere& s = spheres[index];
+            b.grow(mk(s.c[0] - s.r, s.c[1] - s.r, s.c[2] - s.r));
+            b.grow(mk(s.c[0] + s.r, s.c[1] + s.r, s.c[2] + s.r));
+            break;
+        }
+        case RT_SHAPE_QUAD: {
+            const DQuad& q = quads[index];
+            b.grow(ld3(q.p0)); b.grow(ld3(q.p1)); b.grow(ld3(q.p2)); b.grow(ld3(q.p3));
+            break;
+        }
+        case RT_SHAPE_CYLINDER: {
+            const DCylinder& c = cyls[index];
+            for (const double* e : {c.o, c.top}) {
+                b.grow(mk(e[0] - c.r, e[1] - c.r, e[2] - c.r));
+                b.grow(mk(e[0] + c.r, e[1] + c.r, e[2] + c.r));
+            }
+            break;
+        }
+        case RT_SHAPE_TRIANGLE: {
+            const DTri& t = tris[index];
+            b.grow(ld3(t.p0)); b.grow(ld3(t.p1)); b.grow(ld3(t.p2));
+            break;
+        }
+        case RT_SHAPE_MESH: {
+            const DMesh& m = meshes[index];
+            b.grow(ld3(m.root_box)); b.grow(ld3(m.root_box + 3));
+            break;
+        }
+        case RT_SHAPE_TRANSFORMED: {
+            if (depth >= 4) return everything;
+            const DTransformed& x = xforms[index];
+            const Bounds c = shape_bounds(x.child_kind, x.child_index, spheres, quads, cyls, tris, xforms, meshes, depth + 1);
+            // A world ray is taken into the child's frame by x.inv (shape_transformed_shape.go:29-35), so the region of
+            // world space where the child can be hit is the pre-image of its bounds under x.inv -- which is x.fwd's
+            // image only for uniform scales, because Transform.Inverse (transform.go:86-102) is not the exact inverse
+            // otherwise.  Invert x.inv's matrix R * diag(S) numerically.
+            double m[9], im[9];
+            for (int r = 0; r < 3; r++)
+                for (int k = 0; k < 3; k++) m[r * 3 + k] = x.inv.rot[r * 3 + k] * x.inv.sc[k];
+            const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+            if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) return everything;
+            im[0] = (m[4] * m[8] - m[5] * m[7]) / det; im[1] = (m[2] * m[7] - m[1] * m[8]) / det; im[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+            im[3] = (m[5] * m[6] - m[3] * m[8]) / det; im[4] = (m[0] * m[8] - m[2] * m[6]) / det; im[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+            im[6] = (m[3] * m[7] - m[4] * m[6]) / det; im[7] = (m[1] * m[6] - m[0] * m[7]) / det; im[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+            for (int k = 0; k < 8; k++) {
+                const V3 p = mk((k & 1) ? c.hi[0] : c.lo[0], (k & 2) ? c.hi[1] : c.lo[1], (k & 4) ? c.hi[2] : c.lo[2]) - ld3(x.inv.tr);
+                if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) return everything;
+                b.grow(mk(im[0] * p.x + im[1] * p.y + im[2] * p.z, im[3] * p.x + im[4] * p.y + im[5] * p.z, im[6] * p.x + im[7] * p.y + im[8] * p.z));
+            }
+            break;
+        }
+        default: return everything;
+    }
+    double ext = 0, mag = 0;
+    for (int a = 0; a < 3; a++) {
+        if (!(b.lo[a] <= b.hi[a]) || !std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) return everything;
+        ext = std::max(ext, b.hi[a] - b.lo[a]);
+        mag = std::max(mag, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+    }
+    const double pad = 1e-4 * ext + 1e-9 * mag + 1e-300;
+    for (int a = 0; a < 3; a++) { b.lo[a] -= pad; b.hi[a] += pad; }
+    return b;
+}
+
+}  // namespace
+
 int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
     if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
@@ -282,6 +376,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         sc->bvh_info[i] = b.info;
         stack_pairs = std::max(stack_pairs, b.fast_depth + 1);
     }
+    std::vector<double> node_box(d->n_nodes * 6);
+    for (uint64_t i = 0; i < d->n_nodes; i++) {
+        const Bounds b = shape_bounds(nodes[i].kind, nodes[i].index, spheres, quads, cyls, tris, xforms, meshes);
+        std::memcpy(&node_box[i * 6], b.lo, 24);
+        std::memcpy(&node_box[i * 6 + 3], b.hi, 24);
+    }
     std::vector<rt_material> materials(d->materials, d->materials + d->n_materials);
     std::vector<rt_texture> textures(d->textures, d->textures + d->n_textures);
     std::vector<rt_light> lights(d->lights, d->lights + d->n_lights);
@@ -312,6 +412,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HIP_TRY(sc->mem.upload(textures, &dev.textures));
     HIP_TRY(sc->mem.upload(images, &dev.images));
     HIP_TRY(sc->mem.upload(lights, &dev.lights));
+    HIP_TRY(sc->mem.upload(node_box, &dev.node_box));
     sc->all_terminal = true;
     for (const rt_material& m : materials)
         if (m.kind != RT_MAT_EMITTER && m.kind != RT_MAT_DEBUG_UV && m.kind != RT_MAT_DEBUG_NORMAL) sc->all_terminal = false;
@@ -354,7 +455,9 @@ int rt_film_resolve(const double* film_dev, int32_t dx, int32_t dy, int32_t rays
     uint8_t* rgba = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rgba), (size_t)dx * dy * 4));
     launch_resolve(film_dev, dx, dy, rays_per_pixel, rgba, stream);
-    hipError_t e = hipMemcpy2DAsync(rgba_out, stride, rgba, (size_t)dx * 4, (size_t)dx * 4, (size_t)dy, hipMemcpyDeviceToHost, stream);
+    hipError_t e = stride == (size_t)dx * 4
+                       ? hipMemcpyAsync(rgba_out, rgba, (size_t)dx * 4 * (size_t)dy, hipMemcpyDeviceToHost, stream)
+                       : hipMemcpy2DAsync(rgba_out, stride, rgba, (size_t)dx * 4, (size_t)dx * 4, (size_t)dy, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(rgba);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
@@ -367,16 +470,25 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opt
     if (stride < (size_t)opts->dx * 4) return fail(RT_ERR_INVALID, "stride smaller than a row");
     HIP_TRY(hipSetDevice(scene->device));
     double* film = nullptr;
-    uint8_t* rgba = nullptr;
-    if (int rc = scene_film(scene, opts->dx, opts->dy, &film, &rgba)) return rc;
+    uint8_t *rgba = nullptr, *rgba_host = nullptr;
+    if (int rc = scene_film(scene, opts->dx, opts->dy, &film, &rgba, &rgba_host)) return rc;
     const size_t n = (size_t)opts->dx * opts->dy * 3;
     hipStream_t stream = reinterpret_cast<hipStream_t>(opts->stream);
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemsetAsync(film, 0, n * sizeof(double), stream));
     if (int rc = render_into_film(scene, camera, opts, film, stats)) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     launch_resolve(film, opts->dx, opts->dy, opts->rays_per_pixel, rgba, stream);
-    HIP_TRY(hipMemcpy2DAsync(rgba_out, stride, rgba, (size_t)opts->dx * 4, (size_t)opts->dx * 4, (size_t)opts->dy, hipMemcpyDeviceToHost, stream));
+    // device -> pinned staging buffer at full PCIe rate, then rows into the caller's (pageable, possibly strided) image
+    const size_t row = (size_t)opts->dx * 4;
+    HIP_TRY(hipMemcpyAsync(rgba_host, rgba, row * (size_t)opts->dy, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (stride == row) std::memcpy(rgba_out, rgba_host, row * (size_t)opts->dy);
+    else
+        for (int y = 0; y < opts->dy; y++) std::memcpy(rgba_out + (size_t)y * stride, rgba_host + (size_t)y * row, row);
+    if (std::getenv("RT_DEBUG"))
+        fprintf(stderr, "[rt] rt_render: film %.3f ms, resolve + copy out %.3f ms\n", std::chrono::duration<double>(t1 - t0).count() * 1e3,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() * 1e3);
     if (stats) stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
 }

@@ -88,6 +88,7 @@ struct DScene {
     const rt_texture* textures;
     const DImage* images;
     const rt_light* lights;
+    const double* node_box;  // per node: padded world-space bounds (min xyz, max xyz); fast mode skips a node the ray misses
     int32_t n_nodes, n_lights;
     int32_t stack_pairs;  // depth of the deepest fast tree + 1: capacity of the LDS traversal stack
     int32_t pad;
