@@ -16,7 +16,8 @@ struct PassDesc {
     int32_t spp;                    // RaysPerPixel of the whole render
     int32_t sample_begin, sample_count;  // sample indices handled by this pass (each thread loops over them)
     int32_t max_depth;
-    int32_t chunk;                  // sample indices per work item of the primary launch (item = tile x chunk)
+    int32_t log2_s;                 // primary launch: 2^log2_s lanes of a wave trace samples of the same pixel
+    int32_t block_px;               // primary launch: pixels of an 8x8 tile per work item (power of two >= 64 >> log2_s)
     int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group
     int64_t n_pixels;               // tiles * 64 = pixels (threads) of this pass
     uint32_t seed_lo, seed_hi;

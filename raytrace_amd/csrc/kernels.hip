@@ -320,28 +320,41 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 
 // ---- kernels -----------------------------------------------------------------------------------
 
-// renderPixel (render.go:186-217) for one pass.  Persistent single-wave workgroups: each wave pulls
-// work items from a queue until the pass is drained.  An item is an 8x8-pixel tile (thread = pixel) and a
-// run of pass.chunk sample indices: small enough that the slowest items (silhouette tiles cost >10x the
-// mean) cannot leave most of the chip idle at the end of the launch.  Tiles are numbered group by group (8x8 tiles = 64x64 pixels); group g
-// belongs to the queue of XCD g % 8, so the rays an XCD has in flight share BVH nodes in its L2, and a wave
-// whose own queue is empty takes tiles from the other XCDs' queues.  The queue cursors only grow, so every
-// wave reaches the exit after finding all eight queues exhausted.
+// renderPixel (render.go:186-217) for one pass.  Persistent single-wave workgroups pull work items from a
+// queue until the pass is drained.
+//
+// Lanes are dealt to SAMPLES first: a wave traces 2^pass.log2_s samples of each of 64 >> log2_s neighbouring
+// pixels at a time (with 64 or more samples per pass: all 64 lanes on one pixel).  Samples of one pixel differ by
+// a sub-pixel jitter only, so their rays walk the same BVH nodes and test the same faces: the lanes of the wave
+// stay converged through the traversal and its float64 face tests, and read the same cache lines.  The per-pixel
+// sum is a shuffle reduction over the pixel's lanes; one lane adds it to the film (no atomics: a pixel belongs to
+// exactly one item of a launch).
+//
+// An item is pass.block_px consecutive pixels of an 8x8 tile (all the pass's samples of them): small enough that
+// the slowest items (silhouette tiles cost >10x the mean) cannot leave most of the chip idle at the end of the
+// launch.  Tiles are numbered group by group (8x8 tiles = 64x64 pixels); group g belongs to the queue of XCD g % 8,
+// so the rays an XCD has in flight share BVH nodes in its L2, and a wave whose own queue is empty takes items from
+// the other XCDs' queues.  The queue cursors only grow, so every wave reaches the exit after finding all eight
+// queues exhausted.
 template <int MODE, bool MESH_ONLY>
 __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_primary(DScene sc, DCamera cam, PassDesc pass, Queues q, double* __restrict__ film) {
     const int p = (int)threadIdx.x;
     const int64_t n_tiles = pass.n_pixels >> 6;
-    const uint32_t n_chunks = (uint32_t)((pass.sample_count + pass.chunk - 1) / pass.chunk);
+    const int lanes_s = 1 << pass.log2_s;                 // lanes (= samples in flight) per pixel
+    const int px_per_iter = 64 >> pass.log2_s;            // pixels a wave traces at a time
+    const uint32_t n_sub = 64u / (uint32_t)pass.block_px;  // items per tile
+    const int my_px = p >> pass.log2_s, my_s = p & (lanes_s - 1);
+    const int rounds = (pass.sample_count + lanes_s - 1) >> pass.log2_s;
     const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
     uint32_t n_total = 0, n_left = 0;
     for (;;) {
         long long v = -1;
-        uint32_t chunk = 0;
+        uint32_t sub = 0;
         if (p == 0) {
             for (uint32_t k = 0; k < 8 && v < 0; k++) {
                 const uint32_t owner = (xcd + k) & 7;
                 const uint32_t item = atomicAdd(&q.counters->tile_cursor[owner], 1u);
-                const uint32_t idx = item / n_chunks;
+                const uint32_t idx = item / n_sub;
                 long long cand = -1;
                 if (pass.order) {
                     if (idx < pass.queue_len[owner]) cand = pass.order[pass.queue_off[owner] + idx];
@@ -350,66 +363,72 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
                 }
                 if (cand >= 0 && cand < n_tiles) {
                     v = cand;
-                    chunk = item - idx * n_chunks;
+                    sub = item - idx * n_sub;
                 }
             }
         }
         v = __shfl(v, 0, 64);
         if (v < 0) break;
         const long long t_start = pass.cost ? clock64() : 0;
-        chunk = __shfl(chunk, 0, 64);
-        const int k_begin = (int)chunk * pass.chunk;
-        const int k_end = k_begin + pass.chunk < pass.sample_count ? k_begin + pass.chunk : pass.sample_count;
+        sub = __shfl(sub, 0, 64);
         const int64_t tile = pass.tile_begin + v;
         const int64_t group = tile >> 6;
         const int w = (int)(tile & 63);
-        const int lx = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8 + (p & 7);
-        const int ly = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8 + (p >> 3);
-        const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
-        const bool live = lx < pass.dx && ly < pass.local_rows && row < pass.dy;
-        if (__ballot(live) == 0) continue;  // a tile outside the frame: cost stays 0
-        const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
-        const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
-        V3 acc = mk(0, 0, 0);
-        for (int k = k_begin; k < k_end; k++) {
-            const int s = pass.sample_begin + k;
-            bool want = false;
-            Ray r;
-            SceneHit h;
-            PathState ps;
-            if (live) {
-                Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(y * pass.dx + lx), (uint32_t)s, 1u, 0u};
-                double fs, ft;
-                if (pass.spp == 1) {  // render.go:202-210
-                    fs = ((double)lx + 0.5) / (double)pass.dx;
-                    ft = ((double)y + 0.5) / (double)pass.dy;
-                } else {
-                    fs = ((double)lx + rng.float64()) / (double)pass.dx;
-                    ft = ((double)y + rng.float64()) / (double)pass.dy;
+        const int tile_x = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8;
+        const int tile_y = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8;
+        for (int pb = 0; pb < pass.block_px; pb += px_per_iter) {
+            const int pix = (int)sub * pass.block_px + pb + my_px;  // index of this lane's pixel inside the tile, row-major
+            const int lx = tile_x + (pix & 7);
+            const int ly = tile_y + (pix >> 3);
+            const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
+            const bool live = lx < pass.dx && ly < pass.local_rows && row < pass.dy;
+            if (__ballot(live) == 0) continue;  // outside the frame
+            const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
+            const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
+            V3 acc = mk(0, 0, 0);
+            for (int round = 0; round < rounds; round++) {
+                const int k = (round << pass.log2_s) + my_s;
+                const int s = pass.sample_begin + k;
+                bool want = false;
+                Ray r;
+                SceneHit h;
+                PathState ps;
+                if (live && k < pass.sample_count) {
+                    Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(y * pass.dx + lx), (uint32_t)s, 1u, 0u};
+                    double fs, ft;
+                    if (pass.spp == 1) {  // render.go:202-210
+                        fs = ((double)lx + 0.5) / (double)pass.dx;
+                        ft = ((double)y + 0.5) / (double)pass.dy;
+                    } else {
+                        fs = ((double)lx + rng.float64()) / (double)pass.dx;
+                        ft = ((double)y + rng.float64()) / (double)pass.dy;
+                    }
+                    r = camera_cast(cam, fs, ft, rng);
+                    n_total++;
+                    V3 em;
+                    const int what = trace_one<MODE, MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
+                    if (what == 1) acc = acc + em;
+                    want = what == 2;
+                    ps.rad = mk(1, 1, 1);
+                    ps.pixel = pixel;
+                    ps.sample = (uint32_t)s;
+                    ps.path = 1;
+                    ps.depth_n = rng.n;
                 }
-                r = camera_cast(cam, fs, ft, rng);
-                n_total++;
-                V3 em;
-                const int what = trace_one<MODE, MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
-                if (what == 1) acc = acc + em;
-                want = what == 2;
-                ps.rad = mk(1, 1, 1);
-                ps.pixel = pixel;
-                ps.sample = (uint32_t)s;
-                ps.path = 1;
-                ps.depth_n = rng.n;
+                const uint32_t slot = wave_append(&q.counters->shade_count, want);
+                if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
             }
-            const uint32_t slot = wave_append(&q.counters->shade_count, want);
-            if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
-        }
-        if (live) {
-            if (n_chunks == 1) {  // this wave is the only writer of the pixel during the launch
+            // sum over the lanes of a pixel (they are adjacent: xor-shuffles below lanes_s stay inside the pixel)
+            for (int off = lanes_s >> 1; off > 0; off >>= 1) {
+                acc.x += __shfl_xor(acc.x, off, 64);
+                acc.y += __shfl_xor(acc.y, off, 64);
+                acc.z += __shfl_xor(acc.z, off, 64);
+            }
+            if (live && my_s == 0) {  // the only writer of this pixel during the launch
                 double* f = film + (size_t)pixel * 3;
                 if (acc.x != 0) f[0] += acc.x;
                 if (acc.y != 0) f[1] += acc.y;
                 if (acc.z != 0) f[2] += acc.z;
-            } else {
-                film_add(film, pixel, acc);
             }
         }
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));

@@ -308,8 +308,10 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     // samples per pass: enough work per launch (about a 4K frame x 64 samples) that its tail stays small
     int pass_samples = (int)std::min<int64_t>(1024, 64 * std::max<int64_t>(1, 130560 / std::max<int64_t>(tiles_total, 1)));
     if (const char* e = getenv("RT_PASS_SAMPLES")) pass_samples = std::max(1, atoi(e));
-    int chunk_override = 0;  // RT_CHUNK: tuning knob for the samples per work item
-    if (const char* e = getenv("RT_CHUNK")) chunk_override = std::max(1, atoi(e));
+    int lanes_override = -1;   // RT_LOG2_LANES / RT_ITEM_RAYS: tuning knobs of the primary launch
+    int64_t item_rays = 512;
+    if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
+    if (const char* e = getenv("RT_ITEM_RAYS")) item_rays = std::max(1, atoi(e));
     for (int s0 = s_first; s0 < s_end;) {
         // a pass covers all tiles for a run of samples when that fits, else a run of tiles for one sample
         int s_count = 1;
@@ -329,7 +331,19 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             const int64_t nt = std::min(tiles_per_launch, tiles_total - t0);
             pass.sample_begin = s0;
             pass.sample_count = s_count;
-            pass.chunk = chunk_override > 0 ? chunk_override : (s_count >= 32 ? 4 : (s_count >= 2 ? 2 : 1));
+            {   // lanes per pixel: the widest power of two that keeps >= 90 % of the lanes busy over the rounds
+                int log2_s = 0;
+                for (int l = 6; l > 0; l--) {
+                    const int lanes = 1 << l, rounds = (s_count + lanes - 1) / lanes;
+                    if (s_count * 10 >= rounds * lanes * 9) { log2_s = l; break; }
+                }
+                if (lanes_override >= 0) log2_s = std::min(lanes_override, 6);
+                pass.log2_s = log2_s;
+                // pixels per item: about 512 rays, at least what the wave traces at a time, at most the tile
+                int block = 64 >> log2_s;
+                while (block < 64 && (int64_t)block * s_count < item_rays) block <<= 1;
+                pass.block_px = block;
+            }
             pass.tile_begin = t0;
             pass.n_pixels = nt * 64;
             const bool whole = t0 == 0 && nt == tiles_total;
