@@ -153,6 +153,29 @@ struct PairStack {
     }
 };
 
+// A node read through the constant address space: with a wave-uniform index the compiler emits scalar loads
+// (s_load_dwordx4 into SGPRs, served by the scalar data cache) instead of per-lane vector loads.
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+#define RT_CONST_AS __attribute__((address_space(4)))
+RT_DEV FastNode load_node_scalar(const FastNode* nodes, int32_t index) {
+    const RT_CONST_AS i32x4* p = (const RT_CONST_AS i32x4*)(nodes + index);
+    union {
+        i32x4 v[4];
+        FastNode n;
+    } u;
+    u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2]; u.v[3] = p[3];
+    return u.n;
+}
+
+RT_DEV Tri32 load_tri32_scalar(const Tri32* tris, int32_t index) {
+    const RT_CONST_AS i32x4* p = (const RT_CONST_AS i32x4*)(tris + index);
+    union {
+        i32x4 v[3];
+        Tri32 t;
+    } u;
+    u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2];
+    return u.t;
+}
 // Conservative float32 pre-test of a face: true = the float64 test cannot accept this face.
 //
 // Moller-Trumbore without the division: with a = e1.(d x e2), U = s.(d x e2), V = d.(s x e1) the
@@ -207,7 +230,13 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
     bool hit = false;
     for (;;) {
         while (cur >= 0) {  // inner node: test both children, go to the nearer, push the farther
-            const FastNode n = nodes[cur];
+            // When every active lane stands on the same node (the usual case when the lanes of a wave trace samples of
+            // one pixel) the node is fetched once through the scalar cache into SGPRs instead of 64 times through the
+            // vector memory pipeline, whose return path (64 B per clock per CU) is what bounds this loop otherwise.
+            const int32_t ucur = __builtin_amdgcn_readfirstlane(cur);
+            FastNode n;
+            if (__builtin_amdgcn_ballot_w64(cur != ucur) == 0) n = load_node_scalar(nodes, ucur);
+            else n = nodes[cur];
             cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
             float tn[2];
             bool go[2];
@@ -240,17 +269,21 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
             }
         }
         if (cur == kDone) break;
-        {  // leaf
-            const uint32_t code = (uint32_t)~cur;
+        {  // leaf; like the nodes, its float32 faces come through the scalar cache when all active lanes hold the same leaf
+           // (the float64 vertices of the few survivors stay on the vector path: 18 more SGPRs cost more than they save)
+            const int32_t uleaf = __builtin_amdgcn_readfirstlane(cur);
+            const bool uniform = __builtin_amdgcn_ballot_w64(cur != uleaf) == 0;
+            const uint32_t code = (uint32_t)~(uniform ? uleaf : cur);
             const int32_t first = (int32_t)(code >> 3);
             const int32_t count = (int32_t)(code & 7u) + 1;
             for (int32_t q = 0; q < count; q++) {
                 cnt.prims++;
-                const Tri32 t32 = tri32[first + q];
+                const Tri32 t32 = uniform ? load_tri32_scalar(tri32, first + q) : tri32[first + q];
                 if (tri32_rejects(t32, f, dx, dy, dz, err_r, err_d)) continue;
                 const double* p = pos + (int64_t)(first + q) * 9;
+                const V3 p0 = ld3(p), p1 = ld3(p + 3), p2 = ld3(p + 6);
                 double t, u, v;
-                if (mt_core(r, ld3(p), ld3(p + 3), ld3(p + 6), 1e-8, tmin, tmax, t, u, v)) {
+                if (mt_core(r, p0, p1, p2, 1e-8, tmin, tmax, t, u, v)) {
                     hit = true;
                     if (ANY_HIT) return true;
                     tmax = t;
