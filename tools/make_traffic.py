@@ -6,12 +6,17 @@ FETCH_SIZE tallies 128-byte requests at 64 bytes, hence the doubling)."""
 import csv, json, os, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/traffic.json"
+TIMED = int(os.environ.get("TIMED_LAUNCHES", "4"))  # the last launches of the run are bench.py's timed steps
+
+
 def per_launch(group, counter, kernel="k_primary"):
-    tot = 0.0; disp = set()
+    """Mean over the timed launches only: the warm-up step also holds the short pilot launch."""
+    by_dispatch = collections.defaultdict(float)
     for r in csv.DictReader(open(os.path.join(root, group, "pmc_counter_collection.csv"))):
         if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
-            tot += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
-    return tot / max(len(disp), 1), len(disp)
+            by_dispatch[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    last = [by_dispatch[k] for k in sorted(by_dispatch)[-TIMED:]]
+    return sum(last) / max(len(last), 1), len(last)
 f, nf = per_launch("fetch", "FETCH_SIZE")
 w, nw = per_launch("write", "WRITE_SIZE")
 res = {
