@@ -39,7 +39,8 @@ struct Queues {
     uint32_t ray_capacity, shade_capacity, surf_capacity;
 };
 
-void launch_primary(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, int mode, bool mesh_only, double* film,
+// cam and q point to DEVICE copies of the structs
+void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, double* film,
                     hipStream_t s);
 void launch_trace(const DScene& sc, const Queues& q, uint32_t n, int mode, bool mesh_only, double* film, hipStream_t s);
 void launch_shade(const DScene& sc, const PassDesc& pass, const Queues& q, uint32_t n_upper, double* film, hipStream_t s);

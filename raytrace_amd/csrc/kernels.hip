@@ -337,7 +337,12 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // the other XCDs' queues.  The queue cursors only grow, so every wave reaches the exit after finding all eight
 // queues exhausted.
 template <int MODE, bool MESH_ONLY>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_primary(DScene sc, DCamera cam, PassDesc pass, Queues q, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
+    // The camera and the queue descriptors are read through pointers where they are used: as by-value arguments
+    // their ~100 dwords would sit in SGPRs for the whole kernel and push other scalars out into VGPR lanes.
+    const DCamera& cam = *camp;
+    const Queues& q = *qp;
+    Counters* const counters = q.counters;
     const int p = (int)threadIdx.x;
     const int64_t n_tiles = pass.n_pixels >> 6;
     const int lanes_s = 1 << pass.log2_s;                 // lanes (= samples in flight) per pixel
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
         if (p == 0) {
             for (uint32_t k = 0; k < 8 && v < 0; k++) {
                 const uint32_t owner = (xcd + k) & 7;
-                const uint32_t item = atomicAdd(&q.counters->tile_cursor[owner], 1u);
+                const uint32_t item = atomicAdd(&counters->tile_cursor[owner], 1u);
                 const uint32_t idx = item / n_sub;
                 long long cand = -1;
                 if (pass.order) {
@@ -394,14 +399,19 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
                 SceneHit h;
                 PathState ps;
                 if (live && k < pass.sample_count) {
-                    Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(y * pass.dx + lx), (uint32_t)s, 1u, 0u};
+                    // Opaque copies: without them the compiler hoists everything that depends only on the pixel (the first
+                    // Philox round, the int -> double conversions) out of this loop and then has to spill it to scratch
+                    // across the traversal; recomputing a dozen instructions per sample is far cheaper.
+                    int lxv = lx, yv = y;
+                    asm volatile("" : "+v"(lxv), "+v"(yv));
+                    Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(yv * pass.dx + lxv), (uint32_t)s, 1u, 0u};
                     double fs, ft;
                     if (pass.spp == 1) {  // render.go:202-210
-                        fs = ((double)lx + 0.5) / (double)pass.dx;
-                        ft = ((double)y + 0.5) / (double)pass.dy;
+                        fs = ((double)lxv + 0.5) / (double)pass.dx;
+                        ft = ((double)yv + 0.5) / (double)pass.dy;
                     } else {
-                        fs = ((double)lx + rng.float64()) / (double)pass.dx;
-                        ft = ((double)y + rng.float64()) / (double)pass.dy;
+                        fs = ((double)lxv + rng.float64()) / (double)pass.dx;
+                        ft = ((double)yv + rng.float64()) / (double)pass.dy;
                     }
                     r = camera_cast(cam, fs, ft, rng);
                     n_total++;
@@ -415,7 +425,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
                     ps.path = 1;
                     ps.depth_n = rng.n;
                 }
-                const uint32_t slot = wave_append(&q.counters->shade_count, want);
+                const uint32_t slot = wave_append(&counters->shade_count, want);
                 if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
             }
             // sum over the lanes of a pixel (they are adjacent: xor-shuffles below lanes_s stay inside the pixel)
@@ -433,7 +443,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
         }
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
-    wave_tally(q.counters, n_total, n_left, 0);
+    wave_tally(counters, n_total, n_left, 0);
 }
 
 template <int MODE, bool MESH_ONLY>
@@ -680,7 +690,7 @@ static unsigned persistent_grid(K kernel, size_t lds) {
     return cached_grid;
 }
 
-void launch_primary(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, int mode, bool mesh_only, double* film,
+void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, double* film,
                     hipStream_t s) {
     if (pass.n_pixels <= 0) return;
     const size_t lds = stack_bytes(sc, mode);

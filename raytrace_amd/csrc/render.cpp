@@ -23,6 +23,8 @@ struct WorkBuffers {
     DeviceBuffers mem;
     uint32_t q = 0;  // paths per launch at most
     Queues queues{};
+    Queues* d_queues = nullptr;   // device copies read by k_primary
+    DCamera* d_camera = nullptr;
     RayQ pool{};     // overflow stack for generations that outgrow q (Dielectric's two children)
     uint64_t pool_capacity = 0;
     void* pool_base = nullptr;
@@ -127,6 +129,9 @@ int ensure_work(rt_scene* sc) {
     w->queues.ray_capacity = (uint32_t)(2 * qq);
     w->queues.shade_capacity = (uint32_t)qq;
     w->queues.surf_capacity = (uint32_t)qq;
+    HIP_TRY(w->mem.alloc(1, &w->d_queues));
+    HIP_TRY(w->mem.alloc(1, &w->d_camera));
+    HIP_TRY(hipMemcpy(w->d_queues, &w->queues, sizeof(Queues), hipMemcpyHostToDevice));
     return RT_OK;
 }
 
@@ -249,6 +254,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     Queues& q = w.queues;
     hipStream_t stream = reinterpret_cast<hipStream_t>(o->stream);
     sc->cancel.store(false);
+    HIP_TRY(hipMemcpyAsync(w.d_camera, &cam, sizeof(DCamera), hipMemcpyHostToDevice, stream));  // pageable source: staged before the call returns
 
     const auto t_start = std::chrono::steady_clock::now();
     int local_rows = 0;
@@ -355,7 +361,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             EventPair* ev = nullptr;
             HIP_TRY(events.next(&ev));
             HIP_TRY(hipEventRecord(ev->a, stream));
-            launch_primary(sc->dev, cam, pass, q, o->mode, sc->mesh_only, film, stream);
+            launch_primary(sc->dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, film, stream);
             HIP_TRY(hipEventRecord(ev->b, stream));
             HIP_TRY(hipGetLastError());
             traverse_launches++;
