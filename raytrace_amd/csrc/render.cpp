@@ -111,7 +111,7 @@ int ensure_work(rt_scene* sc) {
     if (sc->work) return RT_OK;
     auto* w = new WorkBuffers();
     sc->work = w;
-    w->q = (uint32_t)env_size("RT_QUEUE_RAYS", (size_t)1 << 23);
+    w->q = (uint32_t)env_size("RT_QUEUE_RAYS", (size_t)1 << 25);
     if (w->q < 64 * 64) w->q = 64 * 64;
     const size_t q = w->q;
     char *rays = nullptr, *sray = nullptr, *shit = nullptr, *surfs = nullptr;
