@@ -234,30 +234,35 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
             // one pixel) the node is fetched once through the scalar cache into SGPRs instead of 64 times through the
             // vector memory pipeline, whose return path (64 B per clock per CU) is what bounds this loop otherwise.
             const int32_t ucur = __builtin_amdgcn_readfirstlane(cur);
-            FastNode n;
-            if (__builtin_amdgcn_ballot_w64(cur != ucur) == 0) n = load_node_scalar(nodes, ucur);
-            else n = nodes[cur];
             cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
             float tn[2];
             bool go[2];
+            int32_t child[2];
+            // The slab tests, written once and instantiated for a node held in SGPRs and for one held in VGPRs (the
+            // planes are then direct scalar operands of the packed multiply-adds instead of being copied to VGPRs).
+            auto test_children = [&](const FastNode& n) {
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                // both planes of a slab in one packed fused multiply-add; the rounding of n and of the sum moves a
-                // plane by a few 2^-24 of the mesh radius, well inside the padding of the boxes
-                const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][0], n.b[k][0][1]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
-                const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][0], n.b[k][1][1]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
-                const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][0], n.b[k][2][1]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
-                const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), tmin32));
-                const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), tmax32));
-                tn[k] = tnear;
-                go[k] = (tnear <= tfar) && n.child[k] != kFastEmpty;
-            }
+                for (int k = 0; k < 2; k++) {
+                    // both planes of a slab in one packed fused multiply-add; the rounding of n and of the sum moves a
+                    // plane by a few 2^-24 of the mesh radius, well inside the padding of the boxes
+                    const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][0], n.b[k][0][1]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
+                    const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][0], n.b[k][1][1]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
+                    const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][0], n.b[k][2][1]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
+                    const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), tmin32));
+                    const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), tmax32));
+                    tn[k] = tnear;
+                    go[k] = (tnear <= tfar) && n.child[k] != kFastEmpty;
+                    child[k] = n.child[k];
+                }
+            };
+            if (__builtin_amdgcn_ballot_w64(cur != ucur) == 0) test_children(load_node_scalar(nodes, ucur));
+            else test_children(nodes[cur]);
             if (go[0] && go[1]) {
                 const bool swap = tn[1] < tn[0];
-                st.push(swap ? n.child[0] : n.child[1], swap ? tn[0] : tn[1]);
-                cur = swap ? n.child[1] : n.child[0];
+                st.push(swap ? child[0] : child[1], swap ? tn[0] : tn[1]);
+                cur = swap ? child[1] : child[0];
             } else if (go[0] || go[1]) {
-                cur = go[0] ? n.child[0] : n.child[1];
+                cur = go[0] ? child[0] : child[1];
             } else {
                 cur = kDone;
                 while (st.sp > 0) {  // pop, skipping subtrees that begin beyond the current hit
