@@ -1,9 +1,10 @@
 // HIP kernels of the wavefront path tracer (gfx950).
 //
-//   k_primary   one thread per pixel of a pass, looping over the pass's sample indices: camera ray
-//               -> closest hit -> misses counted, hits on emitting-only materials (Emitter,
-//               DebugUV, DebugNormal) summed in registers and added to the film once; every
-//               other hit is appended (wave64 ballot compaction) to the shade queue
+//   k_primary   renderPixel for the samples of a pass; the lanes of a wave share a pixel (or a few) and
+//               take different samples of it: camera ray -> closest hit -> misses counted, hits on
+//               emitting-only materials (Emitter, DebugUV, DebugNormal) summed over the pixel's lanes
+//               and added to the film once; every other hit is appended (wave64 ballot compaction)
+//               to the shade queue
 //   k_trace     the same for a queued generation of scattered rays, one ray per thread
 //   k_shade     Material.Resolve for the shade queue: children appended to the ray queue,
 //               lit surface points appended for the light loop

@@ -2,7 +2,7 @@
 //
 // The reference hands 16x16 tiles to NumCPU goroutines, each of which recurses through
 // tracePath per sample.  Here the image (this process's row bands of it) is cut into passes of
-// at most `q` paths; a pass is one k_primary launch (pixel per thread, sample loop inside) and
+// at most `q` paths; a pass is one k_primary launch (a persistent grid draining a queue of small pixel blocks) and
 // then, only while some hit needs Material.Resolve, generations of k_shade / k_direct / k_trace.
 // A scene whose materials all just emit (the scan configuration: Emitter + image texture) never
 // leaves k_primary and is rendered without a single host synchronisation per pass.
