@@ -340,6 +340,21 @@ int rt_intersect_batch(rt_scene* scene, const double* o, const double* d, uint64
 int rt_cast_batch(const rt_camera_desc* camera, const double* st, const uint32_t* pixel_sample,
                   uint64_t n, int64_t seed, double* o_out, double* d_out);
 
+/* Reconstruction filters of phys/reconstruct.go:28-87 (1-D, even, compact support). */
+enum rt_recon_filter {
+    RT_RECON_BOX = 0,     /* BoxFilter:  radius 0.5, w = 1 for |x| < 0.5              reconstruct.go:31-43 */
+    RT_RECON_TENT = 1,    /* TentFilter: radius 1,   w = 1 - |x|                      reconstruct.go:47-60 */
+    RT_RECON_MITCHELL = 2 /* MitchellNetravaliFilter, B = C = 1/3, radius 2          reconstruct.go:66-87 */
+};
+
+/* ApplySeparableFilterRGBA (reconstruct.go:95-167) on the device: a horizontal pass from the 8-bit
+ * image (read as Go's 16-bit RGBA(): v * 0x101, / 65535) into float64, a vertical pass back to
+ * 8 bits (uint8(max(0, min(255, 255 * c))), A = 255), edges clamped, weights renormalised per pixel.
+ * rgba_in and rgba_out are HOST images of dx x dy pixels with the given strides in bytes (they may
+ * be the same buffer). */
+int rt_apply_filter(const uint8_t* rgba_in, size_t stride_in, int32_t dx, int32_t dy, int filter,
+                    uint8_t* rgba_out, size_t stride_out);
+
 /* Per-mesh BVH statistics of a created scene (nodes, leaves, depth). */
 typedef struct rt_bvh_info {
     uint64_t n_faces;

@@ -50,6 +50,8 @@ def load():
         lib.oracle_aabb_intersects.argtypes = [P(C.c_double)] * 4
         lib.oracle_aabb_hit.argtypes = [P(C.c_double)] * 4 + [C.c_double, C.c_double]
         lib.oracle_node_bounds.argtypes = [C.c_void_p, C.c_uint64, P(C.c_double)]
+        lib.oracle_apply_filter.argtypes = [P(C.c_uint8), C.c_int32, C.c_int32, C.c_int, P(C.c_uint8)]
+        lib.oracle_apply_filter.restype = C.c_int
         lib.oracle_texture_at.argtypes = [C.c_void_p, C.c_uint64, P(C.c_double), C.c_uint64, P(C.c_double)]
         lib.oracle_random_stream.argtypes = [C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, P(C.c_double)]
         lib.oracle_philox4x32_10.argtypes = [P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
@@ -180,3 +182,14 @@ def sample(which, seed, pixel, sample_idx, normal=(0, 0, 1)):
     out = (C.c_double * 3)()
     assert load().oracle_sample(which, seed, pixel, sample_idx, _d3(normal), out) == 0
     return np.array(out[:])
+
+
+def apply_filter(rgba, filter_kind):
+    """ApplySeparableFilterRGBA (reconstruct.go:95-167) on an (H, W, 4) uint8 image."""
+    lib = load()
+    src = np.ascontiguousarray(rgba, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    rc = lib.oracle_apply_filter(src.ctypes.data_as(C.POINTER(C.c_uint8)), src.shape[1], src.shape[0], int(filter_kind),
+                                 dst.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert rc == 0
+    return dst

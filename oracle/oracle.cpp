@@ -1543,6 +1543,67 @@ int oracle_texture_at(const oracle_scene* s, uint64_t tex, const double* uv, uin
     return RT_OK;
 }
 
+// ApplySeparableFilterRGBA, reconstruct.go:95-167, with the kernels of reconstruct.go:31-87
+// (0 = box, 1 = tent, 2 = Mitchell-Netravali B = C = 1/3).  Packed dx*dy RGBA8 in and out.
+static double recon_eval(int filter, double x) {
+    if (filter == 0) return std::fabs(x) < 0.5 ? 1.0 : 0.0;
+    if (filter == 1) {
+        double ax = std::fabs(x);
+        return ax >= 1 ? 0.0 : 1 - ax;
+    }
+    const double B = 1.0 / 3.0, C = 1.0 / 3.0;
+    x = std::fabs(x);
+    if (x >= 2) return 0;
+    double x2 = x * x, x3 = x2 * x;
+    if (x < 1) return ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B)) / 6.0;
+    return ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C)) / 6.0;
+}
+
+int oracle_apply_filter(const uint8_t* src, int32_t w, int32_t h, int filter, uint8_t* dst) {
+    if (!src || !dst || w <= 0 || h <= 0 || filter < 0 || filter > 2) return RT_ERR_INVALID;
+    const double radius = filter == 0 ? 0.5 : (filter == 1 ? 1.0 : 2.0);
+    std::vector<double> tmp((size_t)w * h * 3);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int x0 = (int)std::floor((double)x - radius), x1 = (int)std::ceil((double)x + radius);
+            if (x0 < 0) x0 = 0;
+            if (x1 > w - 1) x1 = w - 1;
+            double wr = 0, wg = 0, wb = 0, wsum = 0;
+            for (int xi = x0; xi <= x1; xi++) {
+                double wk = recon_eval(filter, (double)x - (double)xi);
+                const uint8_t* p = src + ((size_t)y * w + xi) * 4;
+                double r = (double)((uint32_t)p[0] * 0x101u) / 65535.0;
+                double g = (double)((uint32_t)p[1] * 0x101u) / 65535.0;
+                double b = (double)((uint32_t)p[2] * 0x101u) / 65535.0;
+                wr += wk * r; wg += wk * g; wb += wk * b;
+                wsum += wk;
+            }
+            if (wsum > 0) { wr /= wsum; wg /= wsum; wb /= wsum; }
+            double* t = &tmp[((size_t)y * w + x) * 3];
+            t[0] = wr; t[1] = wg; t[2] = wb;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int y0 = (int)std::floor((double)y - radius), y1 = (int)std::ceil((double)y + radius);
+            if (y0 < 0) y0 = 0;
+            if (y1 > h - 1) y1 = h - 1;
+            double wr = 0, wg = 0, wb = 0, wsum = 0;
+            for (int yi = y0; yi <= y1; yi++) {
+                double wk = recon_eval(filter, (double)y - (double)yi);
+                const double* t = &tmp[((size_t)yi * w + x) * 3];
+                wr += wk * t[0]; wg += wk * t[1]; wb += wk * t[2];
+                wsum += wk;
+            }
+            if (wsum > 0) { wr /= wsum; wg /= wsum; wb /= wsum; }
+            uint8_t* o = dst + ((size_t)y * w + x) * 4;
+            o[0] = (uint8_t)go_max(0, go_min(255, 255.0 * wr));
+            o[1] = (uint8_t)go_max(0, go_min(255, 255.0 * wg));
+            o[2] = (uint8_t)go_max(0, go_min(255, 255.0 * wb));
+            o[3] = 255;
+        }
+    return RT_OK;
+}
+
 // n consecutive Float64 draws of the stream (seed, pixel, sample, path).
 int oracle_random_stream(int64_t seed, uint32_t pixel, uint32_t sample, uint32_t path, uint64_t n, double* out) {
     Rng r;

@@ -9,7 +9,7 @@ _LIB = None
 _PATH = os.environ.get("RT_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_hip.so")
 
 SYMBOLS = [
-    "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
+    "rt_apply_filter", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
     "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info",
 ]
 
@@ -57,6 +57,8 @@ def open_library() -> C.CDLL:
     lib.rt_cast_batch.argtypes = [P(abi.CameraDesc), P(C.c_double), P(C.c_uint32), C.c_uint64, C.c_int64, P(C.c_double),
                                   P(C.c_double)]
     lib.rt_cast_batch.restype = C.c_int
+    lib.rt_apply_filter.argtypes = [P(C.c_uint8), C.c_size_t, C.c_int32, C.c_int32, C.c_int, P(C.c_uint8), C.c_size_t]
+    lib.rt_apply_filter.restype = C.c_int
     lib.rt_scene_bvh_info.argtypes = [C.c_void_p, C.c_uint64, P(abi.BvhInfo)]
     lib.rt_scene_bvh_info.restype = C.c_int
     return lib

@@ -5,6 +5,8 @@ consume these exact structures, so a scene is flattened once and handed to both.
 """
 import ctypes as C
 
+RECON_BOX, RECON_TENT, RECON_MITCHELL = 0, 1, 2  # rt_recon_filter
+
 RT_OK = 0
 RT_ERR_INVALID = -1
 RT_ERR_UNSUPPORTED = -2

@@ -737,6 +737,78 @@ void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode,
         hipLaunchKernelGGL(k_direct<RT_MODE_FAST>, grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, film);
 }
 
+// ---- reconstruction filter (reconstruct.go:28-167) ---------------------------------------------
+
+RT_DEV double recon_radius(int filter) { return filter == RT_RECON_BOX ? 0.5 : (filter == RT_RECON_TENT ? 1.0 : 2.0); }
+
+RT_DEV double recon_eval(int filter, double x) {
+    if (filter == RT_RECON_BOX) return fabs(x) < 0.5 ? 1.0 : 0.0;  // reconstruct.go:35-40
+    if (filter == RT_RECON_TENT) {                                  // reconstruct.go:51-57
+        const double ax = fabs(x);
+        return ax >= 1 ? 0.0 : 1 - ax;
+    }
+    const double B = 1.0 / 3.0, C = 1.0 / 3.0;                      // reconstruct.go:67-85
+    x = fabs(x);
+    if (x >= 2) return 0;
+    const double x2 = x * x, x3 = x2 * x;
+    if (x < 1) return ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B)) / 6.0;
+    return ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C)) / 6.0;
+}
+
+// Horizontal pass (reconstruct.go:103-135): one thread per pixel, taps summed left to right as the reference does.
+__global__ void __launch_bounds__(kBlock) k_filter_h(const uchar4* __restrict__ src, int32_t w, int32_t h, int filter, double* __restrict__ tmp) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= w * h) return;
+    const int x = i % w, y = i / w;
+    const double radius = recon_radius(filter);
+    int x0 = (int)floor((double)x - radius), x1 = (int)ceil((double)x + radius);
+    if (x0 < 0) x0 = 0;
+    if (x1 > w - 1) x1 = w - 1;
+    double wr = 0, wg = 0, wb = 0, wsum = 0;
+    for (int xi = x0; xi <= x1; xi++) {
+        const double wk = recon_eval(filter, (double)x - (double)xi);
+        const uchar4 p = src[(size_t)y * w + xi];
+        const double r = (double)((uint32_t)p.x * 0x101u) / 65535.0;  // color.RGBA.RGBA(): 8 -> 16 bit
+        const double g = (double)((uint32_t)p.y * 0x101u) / 65535.0;
+        const double b = (double)((uint32_t)p.z * 0x101u) / 65535.0;
+        wr += wk * r; wg += wk * g; wb += wk * b;
+        wsum += wk;
+    }
+    if (wsum > 0) { wr /= wsum; wg /= wsum; wb /= wsum; }
+    tmp[(size_t)i * 3 + 0] = wr; tmp[(size_t)i * 3 + 1] = wg; tmp[(size_t)i * 3 + 2] = wb;
+}
+
+// Vertical pass and quantisation (reconstruct.go:138-165).
+__global__ void __launch_bounds__(kBlock) k_filter_v(const double* __restrict__ tmp, int32_t w, int32_t h, int filter, uchar4* __restrict__ dst) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= w * h) return;
+    const int x = i % w, y = i / w;
+    const double radius = recon_radius(filter);
+    int y0 = (int)floor((double)y - radius), y1 = (int)ceil((double)y + radius);
+    if (y0 < 0) y0 = 0;
+    if (y1 > h - 1) y1 = h - 1;
+    double wr = 0, wg = 0, wb = 0, wsum = 0;
+    for (int yi = y0; yi <= y1; yi++) {
+        const double wk = recon_eval(filter, (double)y - (double)yi);
+        const double* p = tmp + ((size_t)yi * w + x) * 3;
+        wr += wk * p[0]; wg += wk * p[1]; wb += wk * p[2];
+        wsum += wk;
+    }
+    if (wsum > 0) { wr /= wsum; wg /= wsum; wb /= wsum; }
+    uchar4 o;
+    o.x = (unsigned char)go_max(0, go_min(255, 255.0 * wr));
+    o.y = (unsigned char)go_max(0, go_min(255, 255.0 * wg));
+    o.z = (unsigned char)go_max(0, go_min(255, 255.0 * wb));
+    o.w = 255;
+    dst[i] = o;
+}
+
+void launch_filter(const uint8_t* src, int32_t w, int32_t h, int filter, double* tmp, uint8_t* dst, hipStream_t s) {
+    const unsigned blocks = blocks_for((uint64_t)w * (uint64_t)h);
+    hipLaunchKernelGGL(k_filter_h, dim3(blocks), dim3(kBlock), 0, s, reinterpret_cast<const uchar4*>(src), w, h, filter, tmp);
+    hipLaunchKernelGGL(k_filter_v, dim3(blocks), dim3(kBlock), 0, s, tmp, w, h, filter, reinterpret_cast<uchar4*>(dst));
+}
+
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s) {
     const int32_t n = dx * dy;
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for((uint64_t)n)), dim3(kBlock), 0, s, film, n, spp, reinterpret_cast<uchar4*>(rgba));

@@ -464,6 +464,26 @@ int rt_film_resolve(const double* film_dev, int32_t dx, int32_t dy, int32_t rays
     return RT_OK;
 }
 
+int rt_apply_filter(const uint8_t* rgba_in, size_t stride_in, int32_t dx, int32_t dy, int filter, uint8_t* rgba_out, size_t stride_out) {
+    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    if (!rgba_in || !rgba_out || dx <= 0 || dy <= 0 || stride_in < (size_t)dx * 4 || stride_out < (size_t)dx * 4)
+        return fail(RT_ERR_INVALID, "bad argument");
+    if (filter < RT_RECON_BOX || filter > RT_RECON_MITCHELL) return fail(RT_ERR_INVALID, "unknown reconstruction filter");
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t row = (size_t)dx * 4, px = (size_t)dx * dy;
+    DeviceBuffers tmp;
+    uint8_t *src = nullptr, *dst = nullptr;
+    double* mid = nullptr;
+    HIP_TRY(tmp.alloc(px * 4, &src));
+    HIP_TRY(tmp.alloc(px * 4, &dst));
+    HIP_TRY(tmp.alloc(px * 3, &mid));
+    HIP_TRY(hipMemcpy2D(src, row, rgba_in, stride_in, row, (size_t)dy, hipMemcpyHostToDevice));
+    launch_filter(src, dx, dy, filter, mid, dst, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2D(rgba_out, stride_out, dst, row, row, (size_t)dy, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, uint8_t* rgba_out, size_t stride, rt_stats* stats) {
     if (!scene || !opts || !rgba_out) return fail(RT_ERR_INVALID, "null argument");
     if (opts->dx <= 0 || opts->dy <= 0) return fail(RT_ERR_INVALID, "bad Dx / Dy must be positive");

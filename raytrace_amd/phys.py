@@ -873,3 +873,39 @@ def Render(scene: Scene, mode=abi.MODE_FAST) -> RenderArtifact:
             return dev.render(scene.Camera[0], scene.RenderOptions, mode)
     except RuntimeError as e:
         raise RuntimeError(f"failed to render scene: {e}")
+
+
+# ---- reconstruction filters (reconstruct.go:16-193) ---------------------------------------------
+
+
+@dataclass
+class ReconFilter:  # reconstruct.go:18-27; the kernel itself lives in the library, selected by `kind`
+    Name: str
+    Radius: float
+    kind: int
+
+
+def BoxFilter() -> ReconFilter:  # reconstruct.go:31-43
+    return ReconFilter("Box(0.5)", 0.5, abi.RECON_BOX)
+
+
+def TentFilter() -> ReconFilter:  # reconstruct.go:47-60
+    return ReconFilter("Tent(1)", 1.0, abi.RECON_TENT)
+
+
+def MitchellNetravaliFilter() -> ReconFilter:  # reconstruct.go:66-87
+    return ReconFilter("Mitchell-Netravali(B=1/3,C=1/3)", 2.0, abi.RECON_MITCHELL)
+
+
+def ApplySeparableFilterRGBA(src: np.ndarray, f: ReconFilter) -> np.ndarray:
+    """reconstruct.go:95-167 on the GPU: (H, W, 4) uint8 in, a new (H, W, 4) uint8 out."""
+    from . import _lib
+    lib = _lib.load()
+    img = np.ascontiguousarray(src, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 4:
+        raise ValueError("expected an (H, W, 4) uint8 image")
+    out = np.empty_like(img)
+    h, w = img.shape[:2]
+    _lib.check(lib.rt_apply_filter(img.ctypes.data_as(C.POINTER(C.c_uint8)), w * 4, w, h, f.kind,
+                                   out.ctypes.data_as(C.POINTER(C.c_uint8)), w * 4), lib)
+    return out
