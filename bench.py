@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on): the scan s
 (icosphere level 8, 1,310,720 faces; the real einstein.obj is not available), Emitter +
 4096^2 bilinear image texture, orthographic camera of example/scan, 3840x2160, 1024 rays per
 pixel, fast mode.  One "step" renders `--spp-step` consecutive sample indices of every pixel of
-the frame (default 64, so 16 steps are the whole 1024-spp frame); the rows of the frame are cut
+the frame (default 256, so 4 steps are the whole 1024-spp frame); the rows of the frame are cut
 into 16-row bands dealt round-robin to the ranks, every rank keeps the whole scene in its own
 HBM, and the per-rank films are gathered onto rank 0 with one RCCL gather after the last step.
 
@@ -30,7 +30,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=4)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--spp-step", type=int, default=64, help="sample indices rendered per step")
+    p.add_argument("--spp-step", type=int, default=256, help="sample indices rendered per step")
     p.add_argument("--level", type=int, default=8, help="icosphere level of the stand-in mesh (8 = 1.31 M faces)")
     p.add_argument("--dx", type=int, default=3840)
     p.add_argument("--dy", type=int, default=2160)
@@ -179,6 +179,7 @@ def main():
             "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.max_depth), "bvh_build_s": info.build_seconds,
             "scene_upload_s": upload_s,
             "rays_per_step_all_gpus": rays_all / max(a.steps, 1),
+            "rank0_kernel_ms_per_step": 1e3 * float(trav_s) / max(a.steps, 1),
         },
     }
     base = None

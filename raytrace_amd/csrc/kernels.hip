@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, PassDesc pass, Queu
 // ComputeDirectLighting's loop body for one (surface point, light) pair
 // (material_lambertian.go:23-52, material_metal.go:68-106, material_dielectric.go:128-170).
 template <int MODE>
-__global__ void __launch_bounds__(kTraceBlock) k_direct(DScene sc, Queues q, uint32_t n_surf, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_direct(DScene sc, Queues q, uint32_t n_surf, double* __restrict__ film) {
     const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = i < n_surf;
     {

@@ -311,8 +311,8 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     }
     if (w.order_valid && w.order_key != order_key) w.order_valid = false;
     constexpr int kPilotSamples = 2;
-    // samples per pass: enough work per launch (about a 4K frame x 64 samples) that its tail stays small
-    int pass_samples = (int)std::min<int64_t>(1024, 64 * std::max<int64_t>(1, 130560 / std::max<int64_t>(tiles_total, 1)));
+    // samples per pass: enough work per launch (about a 4K frame x 256 samples, a tenth of a second) that its tail stays small
+    int pass_samples = (int)std::min<int64_t>(1024, 256 * std::max<int64_t>(1, 130560 / std::max<int64_t>(tiles_total, 1)));
     if (const char* e = getenv("RT_PASS_SAMPLES")) pass_samples = std::max(1, atoi(e));
     int lanes_override = -1;   // RT_LOG2_LANES / RT_ITEM_RAYS: tuning knobs of the primary launch
     int64_t item_rays = 512;
