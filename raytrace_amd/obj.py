@@ -1,0 +1,328 @@
+"""Wavefront OBJ / MTL reader with the semantics of the reference's obj package (obj/obj.go), the converters of
+phys/node.go:101-309 that turn a parsed object into Mesh nodes, and a PNG decoder for `map_Kd` textures.
+
+A "file system" is anything with `read(name) -> bytes`: `DirFS(path)` for a directory, `MapFS({...})` for
+in-memory files (what the reference's tests use, obj_test.go:12-190).  As in the reference, only the base name
+of a path is looked up (obj.go:174-176, 458-461).
+"""
+from __future__ import annotations
+
+import os
+import posixpath
+import struct
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+# ---- file systems -------------------------------------------------------------------------
+
+
+class MapFS:
+    def __init__(self, files: Dict[str, bytes]):
+        self.files = {k: (v.encode() if isinstance(v, str) else bytes(v)) for k, v in files.items()}
+
+    def read(self, name: str) -> bytes:
+        if name not in self.files:
+            raise FileNotFoundError(name)
+        return self.files[name]
+
+
+class DirFS:
+    def __init__(self, root: str):
+        self.root = root
+
+    def read(self, name: str) -> bytes:
+        with open(os.path.join(self.root, name), "rb") as f:
+            return f.read()
+
+
+# ---- parsed object (obj.go:109-155) -----------------------------------------------------------
+
+
+@dataclass
+class Material:  # obj.go:138-145
+    Name: str
+    Diffuse: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    Ambient: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    Specular: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    Shininess: float = 0.0
+    Texture: str = ""
+
+
+@dataclass
+class Face:  # obj.go:132-135; Indices holds (vertex, texcoord, normal), 1-based, 0 = not given
+    Indices: List[Tuple[int, int, int]]
+    Material: str = ""
+
+
+@dataclass
+class Object:  # obj.go:148-154
+    Vertices: List[Tuple[float, float, float]] = field(default_factory=list)
+    TexCoords: List[Tuple[float, float]] = field(default_factory=list)
+    Normals: List[Tuple[float, float, float]] = field(default_factory=list)
+    Faces: List[Face] = field(default_factory=list)
+    Materials: Dict[str, Material] = field(default_factory=dict)
+
+
+class ParseError(ValueError):  # obj.go:157-171
+    def __init__(self, filename, line, line_text, msg):
+        self.Filename, self.Line, self.LineText, self.Msg = filename, line, line_text, msg
+        where = f"{filename}:{line}" if filename else f"line {line}"
+        super().__init__(f"{where}: {msg}\n    {line_text}")
+
+
+def _split_fields(s: str, limit: int) -> List[str]:  # obj.go:664-669
+    return s.split(" ", limit - 1) if limit > 0 else s.split()
+
+
+def _resolve_index(val: int, size: int) -> int:  # obj.go:431-439
+    if val < 0:
+        val = size + val + 1
+    if val < 1 or val > size:
+        raise ValueError(f"index {val} out of range (1 to {size})")
+    return val
+
+
+def ParseFS(fsys, pattern: str) -> Object:  # obj.go:174-195
+    name = posixpath.basename(pattern)
+    try:
+        data = fsys.read(name)
+    except OSError as e:
+        raise ParseError(name, 0, "", f"failed to read file '{pattern}': {e}")
+    obj = Object()
+    current_material = ""
+    text = data.decode("utf-8", errors="replace")
+    for line_no, raw in enumerate(text.split("\n"), start=1):
+        line = raw.strip()
+        if not line or line.startswith("#"):
+            continue
+        sp = line.find(" ")
+        if sp < 0:
+            continue  # a lone token: ignored (obj.go:242-246)
+        directive, rest = line[:sp], line[sp + 1:]
+
+        def err(msg):
+            return ParseError(name, line_no, line, msg)
+
+        if directive == "v" or directive == "vn":  # obj.go:270-290, 312-332
+            what = "vertex" if directive == "v" else "normal"
+            f = _split_fields(rest, 3)
+            if len(f) < 3:
+                raise err(f"invalid {what} data: expected at least 3 components, got {len(f)}")
+            try:
+                xyz = (float(f[0]), float(f[1]), float(f[2]))
+            except ValueError as e:
+                raise err(f"invalid {what} coordinate: {e}")
+            (obj.Vertices if directive == "v" else obj.Normals).append(xyz)
+        elif directive == "vt":  # obj.go:293-309
+            f = _split_fields(rest, 2)
+            if len(f) < 2:
+                raise err(f"invalid texture coordinate data: expected at least 2 components, got {len(f)}")
+            try:
+                obj.TexCoords.append((float(f[0]), float(f[1])))  # a third component is an error, as in the reference
+            except ValueError as e:
+                raise err(f"invalid texture coordinate: {e}")
+        elif directive == "f":  # obj.go:335-356
+            parts = rest.split()
+            if len(parts) < 3:
+                raise err(f"face definition error: a face must have at least 3 vertices, got {len(parts)}")
+            idx = []
+            for part in parts:
+                try:
+                    idx.append(_parse_index(part, obj))
+                except ValueError as e:
+                    raise err(f"invalid face index '{part}': {e}")
+            obj.Faces.append(Face(idx, current_material))
+        elif directive == "usemtl":  # obj.go:442-448
+            if rest == "":
+                raise err("usemtl directive error: material name is missing")
+            current_material = rest
+        elif directive == "mtllib":  # obj.go:451-468
+            if rest == "":
+                raise err("mtllib directive error: filename is missing")
+            for filename in rest.split():
+                base = posixpath.basename(filename)
+                try:
+                    mtl = fsys.read(base)
+                except OSError as e:
+                    raise err(f"failed to read material library '{base}': {e}")
+                _parse_mtl(mtl.decode("utf-8", errors="replace"), base, obj)
+    return obj
+
+
+def _parse_index(s: str, obj: Object) -> Tuple[int, int, int]:  # obj.go:359-428
+    if s == "":
+        raise ValueError("empty face index")
+    parts = s.split("/")
+    if len(parts) > 3:
+        raise ValueError("invalid face index format")
+    v = _resolve_index(int(parts[0]), len(obj.Vertices))
+    vt = vn = 0
+    if len(parts) == 2:
+        vt = _resolve_index(int(parts[1]), len(obj.TexCoords))
+    elif len(parts) == 3:
+        if parts[1] != "":
+            vt = _resolve_index(int(parts[1]), len(obj.TexCoords))
+        if parts[2] != "":
+            vn = _resolve_index(int(parts[2]), len(obj.Normals))
+    return (v, vt, vn)
+
+
+def _parse_mtl(text: str, filename: str, obj: Object) -> None:  # obj.go:471-661
+    current = None
+    for line_no, raw in enumerate(text.split("\n"), start=1):
+        line = raw.strip()
+        if not line or line.startswith("#"):
+            continue
+        sp = line.find(" ")
+        if sp < 0:
+            continue
+        directive, rest = line[:sp], line[sp + 1:]
+
+        def err(msg):
+            return ParseError(filename, line_no, line, msg)
+
+        if directive == "newmtl":
+            if rest == "":
+                raise err("newmtl directive error: material name is missing")
+            current = Material(rest)
+            obj.Materials[rest] = current
+        elif directive in ("Kd", "Ka", "Ks"):
+            if current is None:
+                raise err(f"{directive} directive error: defined before any newmtl")
+            f = _split_fields(rest, 3)
+            if len(f) < 3:
+                raise err(f"{directive} directive error: expected 3 components")
+            try:
+                rgb = (float(f[0]), float(f[1]), float(f[2]))
+            except ValueError as e:
+                raise err(f"invalid {directive} value: {e}")
+            setattr(current, {"Kd": "Diffuse", "Ka": "Ambient", "Ks": "Specular"}[directive], rgb)
+        elif directive == "Ns":
+            if current is None:
+                raise err("Ns directive error: defined before any newmtl")
+            try:
+                current.Shininess = float(_split_fields(rest, 1)[0])
+            except ValueError as e:
+                raise err(f"invalid Ns value: {e}")
+        elif directive == "map_Kd":
+            if current is None:
+                raise err("map_Kd directive error: defined before any newmtl")
+            if rest == "":
+                raise err("map_Kd directive error: expected a filename")
+            current.Texture = rest
+
+
+# ---- PNG (what image/png.Decode gives NewTextureImageFS, texture_image.go:33-49) --------------
+
+
+def decode_png(data: bytes) -> np.ndarray:
+    """Non-interlaced PNG of colour type 0, 2, 3, 4 or 6 and bit depth 8 or 16 (1/2/4 for palettes and gray).
+    Returns (H, W, 4) uint8 non-premultiplied NRGBA for depths <= 8 and (H, W, 4) uint16 alpha-premultiplied
+    RGBA for 16-bit files: the two layouts phys.TextureImage accepts (what Go's Color.RGBA() reports)."""
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("png: invalid format: not a PNG file")
+    pos, idat, palette, trns, hdr = 8, [], None, None, None
+    while pos + 8 <= len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if kind == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"PLTE":
+            palette = np.frombuffer(body, dtype=np.uint8).reshape(-1, 3)
+        elif kind == b"tRNS":
+            trns = body
+        elif kind == b"IDAT":
+            idat.append(body)
+        elif kind == b"IEND":
+            break
+    if hdr is None:
+        raise ValueError("png: missing IHDR")
+    w, h, depth, ctype, _, _, interlace = hdr
+    if interlace:
+        raise ValueError("png: interlaced files are not supported")
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}.get(ctype)
+    if channels is None or depth not in (1, 2, 4, 8, 16) or (depth < 8 and ctype not in (0, 3)):
+        raise ValueError("png: unsupported colour type / bit depth")
+    raw = zlib.decompress(b"".join(idat))
+    bpp = max(1, channels * depth // 8)  # bytes per complete pixel, for the filters
+    stride = (w * channels * depth + 7) // 8
+    rows = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft = raw[y * (stride + 1)]
+        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=y * (stride + 1) + 1).astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:  # Sub, Average and Paeth depend on the pixel to the left: byte-serial per row
+            cur = line.copy()
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 1:
+                    pred = a
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                elif ft == 4:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                else:
+                    raise ValueError("png: bad filter type")
+                cur[i] = (cur[i] + pred) & 255
+        rows[y] = cur
+        prev = cur
+    if depth == 16:
+        px = rows.reshape(h, -1, 2).astype(np.uint32)
+        px = ((px[..., 0] << 8) | px[..., 1]).reshape(h, w, channels)
+        full = 65535
+    elif depth == 8:
+        px = rows.reshape(h, w, channels).astype(np.uint32)
+        full = 255
+    else:  # packed gray / palette indices
+        bits = np.unpackbits(rows, axis=1)[:, :w * depth].reshape(h, w, depth)
+        px = bits.dot(1 << np.arange(depth - 1, -1, -1)).astype(np.uint32)[..., None]
+        full = (1 << depth) - 1
+    out = np.empty((h, w, 4), dtype=np.uint32)
+    if ctype == 3:
+        if palette is None:
+            raise ValueError("png: palette missing")
+        idx = px[..., 0]
+        out[..., :3] = palette[idx]
+        alpha = np.full(256, 255, dtype=np.uint32)
+        if trns is not None:
+            alpha[:len(trns)] = np.frombuffer(trns, dtype=np.uint8)
+        out[..., 3] = alpha[idx]
+        return out.astype(np.uint8)
+    if ctype in (0, 4):
+        g = px[..., 0] * (255 // full) if depth < 8 else px[..., 0]
+        out[..., 0] = out[..., 1] = out[..., 2] = g
+        out[..., 3] = px[..., 1] if ctype == 4 else (65535 if depth == 16 else 255)
+    else:
+        out[..., :3] = px[..., :3]
+        out[..., 3] = px[..., 3] if ctype == 6 else (65535 if depth == 16 else 255)
+    if depth == 16:  # NRGBA64 -> premultiplied, as color.NRGBA64.RGBA() does
+        a = out[..., 3:4].astype(np.uint64)
+        out[..., :3] = (out[..., :3].astype(np.uint64) * a // 0xffff).astype(np.uint32)
+        return out.astype(np.uint16)
+    return out.astype(np.uint8)
+
+
+def encode_png_rgba8(img: np.ndarray) -> bytes:
+    """Minimal writer (filter 0, one IDAT) for (H, W, 4) uint8 images; used by tests and for saving renders."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + \
+        chunk(b"IEND", b"")

@@ -909,3 +909,92 @@ def ApplySeparableFilterRGBA(src: np.ndarray, f: ReconFilter) -> np.ndarray:
     _lib.check(lib.rt_apply_filter(img.ctypes.data_as(C.POINTER(C.c_uint8)), w * 4, w, h, f.kind,
                                    out.ctypes.data_as(C.POINTER(C.c_uint8)), w * 4), lib)
     return out
+
+
+# ---- OBJ -> nodes (node.go:101-309) and file textures (texture_image.go:33-84) ------------------
+
+
+def NewTextureImageFS(fsys, file_path: str, interp: str = "", wrap_mode: str = "") -> TextureImage:  # texture_image.go:33-49
+    from . import obj as _obj
+    return TextureImage(_obj.decode_png(fsys.read(file_path)), interp, wrap_mode, file_path)
+
+
+def NewTextureImage(file_path: str, interp: str = "", wrap_mode: str = "") -> TextureImage:  # texture_image.go:60-84
+    from . import obj as _obj
+    with open(file_path, "rb") as f:
+        return TextureImage(_obj.decode_png(f.read()), interp, wrap_mode, file_path)
+
+
+def _faces_of(src, faces) -> np.ndarray:
+    """Fan triangulation + vertex lookup + Face.Validate filtering (node.go:121-150, 172-193): (n, 3, 5) float64."""
+    pos = np.asarray(src.Vertices, dtype=np.float64).reshape(-1, 3)
+    tex = np.asarray(src.TexCoords, dtype=np.float64).reshape(-1, 2)
+    tri = []
+    for face in faces:
+        idx = face.Indices
+        if len(idx) < 3:
+            continue
+        for i in range(1, len(idx) - 1):
+            tri.append((idx[0], idx[i], idx[i + 1]))
+    if not tri:
+        return np.zeros((0, 3, 5))
+    t = np.asarray(tri, dtype=np.int64)  # (n, 3 corners, (v, vt, vn))
+    v = t[..., 0] - 1
+    if (v < 0).any() or (v >= len(pos)).any():
+        raise ValueError("vertex index out of range")
+    out = np.zeros((len(t), 3, 5))
+    out[..., :3] = pos[v]
+    vt = t[..., 1]
+    has = (vt > 0) & (vt - 1 < len(tex))  # no texture coordinate: uv = (0, 0)
+    if len(tex):
+        out[..., 3:] = np.where(has[..., None], tex[np.clip(vt - 1, 0, len(tex) - 1)], 0.0)
+    # Face.Validate (shape_mesh.go:23-91): finite, no two identical vertices, area >= 1e-12; failing faces are skipped
+    p0, p1, p2 = out[:, 0, :3], out[:, 1, :3], out[:, 2, :3]
+    ok = np.isfinite(out).all(axis=(1, 2))
+    ok &= ~((p0 == p1).all(1) | (p0 == p2).all(1) | (p1 == p2).all(1))
+    with np.errstate(invalid="ignore", over="ignore"):
+        area = 0.5 * np.linalg.norm(np.cross(p1 - p0, p2 - p0), axis=1)
+    ok &= ~(area < 1e-12)
+    return np.ascontiguousarray(out[ok])
+
+
+def ConvertObjectToShape(src) -> Mesh:  # node.go:195-232
+    return Mesh(_faces_of(src, src.Faces))
+
+
+def ConvertObjectToMaterial(src, asset_fs) -> dict:  # node.go:266-309
+    materials = {}
+    for name, mat in src.Materials.items():
+        if mat.Texture != "":
+            try:
+                tex = NewTextureImageFS(asset_fs, mat.Texture, "bilinear", "repeat")
+            except Exception as e:
+                raise ValueError(f"failed to load texture '{mat.Texture}' for material '{name}': {e}")
+        else:
+            tex = TextureUniform(tuple(mat.Diffuse))
+        m = Emitter(tex)
+        m.Validate()
+        materials[name] = m
+    if not materials:
+        materials["default"] = Emitter(TextureUniform((0.8, 0.8, 0.8)))
+    return materials
+
+
+def ConvertObjectToNodes(src, asset_fs) -> list:  # node.go:101-169
+    """One Mesh node per material name.  The reference iterates a Go map, so its node order is unspecified;
+    here nodes come in order of first use, which is stable."""
+    materials = ConvertObjectToMaterial(src, asset_fs)
+    groups: dict = {}
+    for face in src.Faces:
+        groups.setdefault(face.Material or "default", []).append(face)
+    nodes = []
+    for name, faces in groups.items():
+        mesh = NewMesh(_faces_of(src, faces))
+        material = materials.get(name, materials.get("default"))
+        node = Node(name, mesh, material)
+        try:
+            node.Validate()
+        except (ValueError, AttributeError) as e:
+            raise ValueError(f"invalid node for material '{name}': {e}")
+        nodes.append(node)
+    return nodes

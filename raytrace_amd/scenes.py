@@ -292,6 +292,38 @@ def scan(level=8, dx=3840, dy=2160, spp=1024, depth=10, seed=0, tex_size=4096, l
                       RenderOptions=phys.RenderOptions(seed, spp, depth, dx, dy))
 
 
+def scan_from_obj(fsys, model_path, dx=512, dy=512, spp=1, depth=10, seed=0, step=0, nstep=4) -> phys.Scene:
+    """example/scan/main.go:71-150: parse the OBJ (with its MTL and PNG texture) from `fsys`, one Mesh node per
+    material (Emitter + texture), no lights, and the orthographic camera number `step` of the example's orbit
+    (LookFrom = (100 m cos t, 100 m sin t, 100 m - 80 m sin t), FOV 250 units; the example renders camera 0)."""
+    from . import obj
+    parsed = obj.ParseFS(fsys, model_path)
+    nodes = phys.ConvertObjectToNodes(parsed, fsys)
+    cams = []
+    for i in range(nstep):
+        t = i * 2.0 * math.pi / nstep
+        cams.append(phys.OrthographicCamera(LookFrom=(100.0 * M * math.cos(t), 100.0 * M * math.sin(t), 100.0 * M - 80.0 * math.sin(t) * M),
+                                            LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0), FOVHeight=250.0, FOVWidth=250.0))
+    cams = cams[step % nstep:] + cams[:step % nstep]
+    return phys.Scene(Camera=cams, Node=nodes, Light=[], RenderOptions=phys.RenderOptions(seed, spp, depth, dx, dy))
+
+
+def write_obj(faces: np.ndarray, mtl_name="scan.mtl", material="scan", texture="scan.png") -> tuple:
+    """(obj text, mtl text) for an (n, 3, 5) face array: unshared v / vt per corner, '%.17g' so that parsing
+    gives back the same float64 values."""
+    f = np.asarray(faces, dtype=np.float64).reshape(-1, 3, 5)
+    lines = [f"mtllib {mtl_name}"]
+    for v in f.reshape(-1, 5):
+        lines.append("v %.17g %.17g %.17g" % (v[0], v[1], v[2]))
+    for v in f.reshape(-1, 5):
+        lines.append("vt %.17g %.17g" % (v[3], v[4]))
+    lines.append(f"usemtl {material}")
+    for i in range(len(f)):
+        a = 3 * i + 1
+        lines.append(f"f {a}/{a} {a + 1}/{a + 1} {a + 2}/{a + 2}")
+    return "\n".join(lines) + "\n", f"newmtl {material}\nKd 1 1 1\nmap_Kd {texture}\n"
+
+
 def material(dx=2048, dy=2048, spp=4096, depth=5, seed=0, tex_size=(564, 568)) -> phys.Scene:
     """example/material/main.go:29-123: the sphere grid of Lambertian / Dielectric / Metal /
     debug materials, three axis cylinders, orthographic camera with VUp = X, one point

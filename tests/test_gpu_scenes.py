@@ -232,3 +232,24 @@ def test_reconstruction_filter_properties():
         assert np.abs(out[..., :3].astype(int) - 200).max() <= 1
     with pytest.raises(RuntimeError, match="unknown reconstruction filter"):
         phys.ApplySeparableFilterRGBA(flat, phys.ReconFilter("x", 1.0, 7))
+
+
+def test_obj_route_renders_the_same_image_as_the_direct_route(ob):
+    """example/scan end to end: mesh -> OBJ + MTL + PNG text -> ParseFS -> ConvertObjectToNodes -> render, against
+    the same mesh and texture handed over directly."""
+    from raytrace_amd import obj
+    faces = scenes.scan_standin_mesh(4)
+    tex = scenes.procedural_texture(64)
+    obj_text, mtl_text = scenes.write_obj(faces)
+    fsys = obj.MapFS({"scan.obj": obj_text, "scan.mtl": mtl_text, "scan.png": obj.encode_png_rgba8(tex)})
+    via_obj = scenes.scan_from_obj(fsys, "models/scan.obj", dx=160, dy=120, spp=2)
+    assert len(via_obj.Node) == 1 and np.array_equal(via_obj.Node[0].Shape.Face, faces)
+    direct = phys.Scene(Camera=via_obj.Camera, Node=[phys.Node("scan", phys.NewMesh(faces), phys.Emitter(phys.TextureImage(tex, "bilinear", "repeat")))],
+                        RenderOptions=via_obj.RenderOptions)
+    a = phys.Render(via_obj)
+    b = phys.Render(direct)
+    assert np.array_equal(a.Image, b.Image) and a.Stats.TotalRays == b.Stats.TotalRays == 160 * 120 * 2
+    assert a.Image[..., :3].max() > 50
+    with ob.OracleScene(via_obj) as orc:
+        img, st, _, _ = orc.render(via_obj.Camera[0], via_obj.RenderOptions)
+    assert np.abs(a.Image.astype(int) - img.astype(int)).max() <= 1
