@@ -15,9 +15,12 @@ RT_DEV void texel16(const DImage& im, int x, int y, uint32_t c[3]) {
         const uchar4 q = reinterpret_cast<const uchar4*>(im.px)[(size_t)y * im.w + x];
         const uint32_t a = q.w;
         uint32_t r = q.x, g = q.y, b = q.z;
-        r |= r << 8; r *= a; r /= 0xff;
-        g |= g << 8; g *= a; g /= 0xff;
-        b |= b << 8; b *= a; b /= 0xff;
+        r |= r << 8; g |= g << 8; b |= b << 8;
+        if (a != 0xff) {  // opaque texels (nearly all of them) keep v * 0x101: v * 0x101 * 255 / 255
+            r *= a; r /= 0xff;
+            g *= a; g /= 0xff;
+            b *= a; b /= 0xff;
+        }
         c[0] = r; c[1] = g; c[2] = b;
     }
 }
