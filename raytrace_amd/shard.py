@@ -37,14 +37,17 @@ def combine_films(film, dst: int = 0):
     most = max(len(r) for r in rows)  # gather needs equal-sized pieces: pad the short ones
     mine = torch.zeros((most,) + tuple(film.shape[1:]), dtype=film.dtype, device=film.device)
     mine[:len(rows[rank])] = film.index_select(0, rows[rank])
+    # gloo (CPU rehearsals of the multi-rank path) moves host tensors only
+    via_host = dist.get_backend() == "gloo" and mine.is_cuda
+    send = mine.cpu() if via_host else mine
     if rank == dst:
-        pieces = [torch.empty_like(mine) for _ in range(world)]
-        dist.gather(mine, pieces, dst=dst)
+        pieces = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, pieces, dst=dst)
         for r in range(world):
             if r != dst:
-                film.index_copy_(0, rows[r], pieces[r][:len(rows[r])])
+                film.index_copy_(0, rows[r], pieces[r][:len(rows[r])].to(film.device))
     else:
-        dist.gather(mine, None, dst=dst)
+        dist.gather(send, None, dst=dst)
     return film
 
 
@@ -53,6 +56,8 @@ def combine_counters(values):
     import torch.distributed as dist
     total, worst = values.clone(), values.clone()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo" and values.is_cuda:
+            total, worst = total.cpu(), worst.cpu()
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     return total, worst
