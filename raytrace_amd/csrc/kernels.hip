@@ -43,6 +43,9 @@ extern __shared__ int32_t dyn_lds[];
 struct SceneHit {
     int node, prim;
     Col c;
+    // Mesh-only scenes leave the attributes of the winning face to finish_hit(): most hits (emitters) need the
+    // texture coordinates only, not the normal (a square root and three divisions) or the hit point.
+    int leaf;      // >= 0: position of the face in leaf order, attributes pending; c.u / c.v hold the barycentrics
 };
 
 template <int MODE>
@@ -108,6 +111,23 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
     return hit;
 }
 
+// Attributes of a pending mesh hit (shape_mesh.go:125-141): everything, or just the texture coordinates.
+RT_DEV void finish_hit(const DScene& sc, const Ray& r, SceneHit& h, bool full) {
+    if (h.leaf < 0) return;
+    const DMesh& m = sc.meshes[sc.nodes[h.node].index];
+    const double u = h.c.u, v = h.c.v;
+    const double* uv6 = sc.face_uv + (m.face_off + h.prim) * 6;
+    if (full) {
+        const double* pos = sc.prim_pos + (m.prim_off + h.leaf) * 9;
+        face_finish(r, ld3(pos), ld3(pos + 3), ld3(pos + 6), uv6, h.c.t, u, v, h.c);
+    } else {
+        const double w = 1 - u - v;
+        h.c.u = (uv6[0] * w + uv6[2] * u) + uv6[4] * v;
+        h.c.v = (uv6[1] * w + uv6[3] * u) + uv6[5] * v;
+    }
+    h.leaf = -1;
+}
+
 // Fast mode only: can the ray reach node i's padded bounds within [tmin, tmax]?  fmin / fmax drop the NaN of
 // 0 * inf (origin on a slab plane of an axis the ray does not move along): that axis then does not constrain.
 RT_DEV bool node_box_reachable(const double* b, const Ray& r, V3 inv, double tmin, double tmax) {
@@ -128,13 +148,30 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
     const bool cull = MODE == RT_MODE_FAST && !MESH_ONLY;  // a mesh clips the ray against its own root box
     V3 inv = mk(0, 0, 0);
     if (cull) inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    h.leaf = -1;
     for (int i = 0; i < sc.n_nodes; i++) {
         const DNode nd = sc.nodes[i];
+        if (MESH_ONLY) {  // Mesh.Collide without the attributes: finish_hit() computes what the caller needs
+            const DMesh& m = sc.meshes[nd.index];
+            double t, u, v;
+            int p = 0;
+            bool got;
+            if (MODE == RT_MODE_REFERENCE) got = mesh_collide_ref(sc, m, r, tmin, min_dist, p, t, u, v, cnt);
+            else got = mesh_collide_fast<false>(sc, m, r, tmin, min_dist, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt);
+            if (got && t < min_dist) {
+                min_dist = t;
+                h.c.t = t; h.c.u = u; h.c.v = v;
+                h.node = i;
+                h.leaf = p;
+                h.prim = sc.prim_face[m.prim_off + p];
+                hit = true;
+            }
+            continue;
+        }
         if (cull && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
         Col c;
         int prim;
-        const bool got = MESH_ONLY ? mesh_node_collide<MODE>(sc, nd.index, r, tmin, min_dist, c, prim, cnt, ls)
-                                   : shape_collide<MODE>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, ls);
+        const bool got = shape_collide<MODE>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, ls);
         if (got && c.t < min_dist) {
             min_dist = c.t;
             h.c = c;
@@ -313,9 +350,11 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
     }
     const rt_material& m = sc.materials[sc.nodes[h.node].material];
     if (terminal_kind(m.kind)) {
+        finish_hit(sc, r, h, m.kind == RT_MAT_DEBUG_NORMAL);
         emission = terminal_emission(sc, m, h.c, rad);
         return 1;
     }
+    finish_hit(sc, r, h, true);
     return 2;
 }
 
