@@ -30,7 +30,8 @@ def build():
 def load():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(_PATH):
+        src = os.path.join(_DIR, "oracle.cpp")
+        if not os.path.exists(_PATH) or os.path.getmtime(_PATH) < os.path.getmtime(src):
             build()
         lib = C.CDLL(_PATH)
         P = C.POINTER

@@ -19,8 +19,11 @@ def declared_functions():
 def library():
     from raytrace_amd import _lib
     path = _lib.lib_path()
-    if not os.path.exists(path):
-        pytest.fail(f"{path} is missing: run `python __graft_entry__.py` (build()) first")
+    if not os.path.exists(path):  # a fresh checkout: the library is a build product, not a tracked file
+        import sys
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
     return _lib.open_library()
 
 
