@@ -267,3 +267,22 @@ def test_random_stream_distribution():
         nrm = unit((0.3, -0.5, 0.8))
         d = ob.sample(2, 1, i, 0, nrm)
         assert abs(np.linalg.norm(d) - 1) < 1e-12 and d @ nrm >= 0
+
+
+def test_r3_table_tests():
+    """r3/vec_test.go: TestVecSub, Mul, Muls, Divs, Dot, Cross, Length, Unit, Lerp (clamped), Clip (transcribed)."""
+    from oracle import binding as ob
+    v1, v2 = (1, 2, 3), (4, 5, 6)
+    assert np.array_equal(ob.r3(1, v1, v2), [-3, -3, -3])
+    assert np.array_equal(ob.r3(2, v1, v2), [4, 10, 18])
+    assert np.array_equal(ob.r3(3, v1, s=2.0), [2, 4, 6])
+    assert np.array_equal(ob.r3(4, (2, 4, 6), s=2.0), [1, 2, 3])
+    assert np.isinf(ob.r3(4, (2, 4, 6), s=0.0)).all()  # Divs(0): IEEE infinities, as in Go
+    assert ob.r3(5, v1, v2) == 32.0
+    assert np.array_equal(ob.r3(6, v1, v2), [-3, 6, -3])
+    assert ob.r3(7, (3, 4, 0)) == 5.0
+    assert np.allclose(ob.r3(8, (3, 4, 0)), [0.6, 0.8, 0], atol=1e-6, rtol=0)
+    assert np.array_equal(ob.r3(8, (0, 0, 0)), [0, 0, 0])
+    for t, want in ((0, 0), (0.5, 5), (1, 10), (-0.5, 0), (1.5, 10)):  # TestVecLerp: the parameter is clamped to [0, 1]
+        assert np.array_equal(ob.r3(9, (0, 0, 0), (10, 10, 10), s=t), [want] * 3)
+    assert np.array_equal(ob.r3(10, (-2, 0, 2), s=-1.0, t=1.0), [-1, 0, 1])
