@@ -392,24 +392,34 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
     const int rounds = (pass.sample_count + lanes_s - 1) >> pass.log2_s;
     const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
     uint32_t n_total = 0, n_left = 0;
+    // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
+    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
+        const uint32_t item = atomicAdd(&counters->tile_cursor[owner], 1u);
+        const uint32_t idx = item / n_sub;
+        long long cand = -1;
+        if (pass.order) {
+            if (idx < pass.queue_len[owner]) cand = pass.order[pass.queue_off[owner] + idx];
+        } else {
+            cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
+        }
+        tile_out = (cand >= 0 && cand < n_tiles) ? cand : -1;
+        sub_out = item - idx * n_sub;
+    };
+    // The item after the current one is drawn from the wave's own queue while the current one is traced, so the
+    // round trip of the atomic (and of the order look-up) is off the critical path.
+    long long ahead_v = -1;
+    uint32_t ahead_sub = 0;
+    if (p == 0) draw(xcd, ahead_v, ahead_sub);
     for (;;) {
         long long v = -1;
         uint32_t sub = 0;
         if (p == 0) {
-            for (uint32_t k = 0; k < 8 && v < 0; k++) {
-                const uint32_t owner = (xcd + k) & 7;
-                const uint32_t item = atomicAdd(&counters->tile_cursor[owner], 1u);
-                const uint32_t idx = item / n_sub;
-                long long cand = -1;
-                if (pass.order) {
-                    if (idx < pass.queue_len[owner]) cand = pass.order[pass.queue_off[owner] + idx];
-                } else {
-                    cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
-                }
-                if (cand >= 0 && cand < n_tiles) {
-                    v = cand;
-                    sub = item - idx * n_sub;
-                }
+            if (ahead_v >= 0) {
+                v = ahead_v;
+                sub = ahead_sub;
+                draw(xcd, ahead_v, ahead_sub);
+            } else {  // own queue exhausted (cursors only grow): take from the other XCDs' queues
+                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub);
             }
         }
         v = __shfl(v, 0, 64);
