@@ -260,3 +260,45 @@ def test_obj_route_renders_the_same_image_as_the_direct_route(ob):
     with ob.OracleScene(via_obj) as orc:
         img, st, _, _ = orc.render(via_obj.Camera[0], via_obj.RenderOptions)
     assert np.abs(a.Image.astype(int) - img.astype(int)).max() <= 1
+
+
+def test_full_size_teapot_frame_properties():
+    """BASELINE configs[1] at its full size (1920x1080, 256 spp, metal mesh on a checkerboard, two lights), checked
+    through properties: counter identities, additivity over sample ranges and over row bands (float64 atomics
+    add in a different order, hence the tolerance)."""
+    import torch
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    sc = scenes.teapot(1920, 1080, 256, 6)
+    o = sc.RenderOptions
+    cd = phys.camera_desc(sc.Camera[0])
+
+    def film_of(dev, s0, cnt, rank=0, world=1, into=None):
+        film = into if into is not None else torch.zeros((o.Dy, o.Dx, 3), dtype=torch.float64, device="cuda")
+        ro = phys.render_opts(o, abi.MODE_FAST, rank, world, None, s0, cnt)
+        st = abi.Stats()
+        _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
+        torch.cuda.synchronize()
+        return film, st
+
+    with phys.DeviceScene(sc) as dev:
+        whole, st = film_of(dev, 0, 256)
+        primaries = 1920 * 1080 * 256
+        assert primaries < st.total_rays < 4 * primaries          # every hit scatters at most one child per level here
+        assert 0 < st.rays_left_scene <= st.total_rays
+        assert st.rays_exceeded_depth < 0.05 * st.total_rays
+        assert st.shadow_rays % 2 == 0 and st.shadow_rays > primaries  # two lights per lit surface point
+        parts, a = film_of(dev, 0, 100)
+        _, b = film_of(dev, 100, 156, into=parts)
+        assert a.total_rays + b.total_rays == st.total_rays
+        assert a.shadow_rays + b.shadow_rays == st.shadow_rays
+        assert torch.allclose(parts, whole, rtol=1e-9, atol=1e-9)
+        acc = torch.zeros_like(whole)
+        rays = 0
+        for rank in range(2):
+            f, s = film_of(dev, 0, 256, rank, 2)
+            acc += f
+            rays += s.total_rays
+        assert rays == st.total_rays
+        assert torch.allclose(acc, whole, rtol=1e-9, atol=1e-9)
+        assert whole.mean().item() > 1.0  # radiance sums over 256 samples: the frame is lit
