@@ -174,15 +174,21 @@ RT_DEV void resolve(const DScene& sc, const rt_material& m, V3 d, V3 in_rad, con
             if (ok) {
                 reflect_prob = reflectance(cosine, n1, n2);
                 if (m.roughness > 0) refracted = unit(refracted + in_unit_sphere(rng) * m.roughness);
-                out.dir[out.n] = refracted;
-                out.rad[out.n] = in_rad * (1 - reflect_prob);
-                out.n++;
             }
             V3 reflected = reflect_ray(d, c.normal);
             if (m.roughness > 0) reflected = unit(reflected + in_unit_sphere(rng) * m.roughness);
-            out.dir[out.n] = reflected;
-            out.rad[out.n] = in_rad * reflect_prob;
-            out.n++;
+            // the returned slice holds the refracted ray first when there is one (fixed slots: no indexed stores)
+            if (ok) {
+                out.dir[0] = refracted;
+                out.rad[0] = in_rad * (1 - reflect_prob);
+                out.dir[1] = reflected;
+                out.rad[1] = in_rad * reflect_prob;
+                out.n = 2;
+            } else {
+                out.dir[0] = reflected;
+                out.rad[0] = in_rad * reflect_prob;
+                out.n = 1;
+            }
             break;
         }
         case RT_MAT_EMITTER: {  // material_emitter.go:22-25

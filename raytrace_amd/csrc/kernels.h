@@ -31,19 +31,18 @@ struct PassDesc {
 };
 
 struct Queues {
-    RayQ rays;      // generation being traced / children appended by k_shade
-    RayQ shade_ray; // rays whose hit needs Material.Resolve ...
-    HitQ shade_hit; // ... and their collisions (same index)
-    SurfQ surfs;    // lit surface points of this generation
+    RayQ rays[2];   // two generations: a launch traces rays[in] and appends the scattered children to rays[out]
+    SurfQ surfs;    // lit surface points of the generation being shaded
     Counters* counters;
-    uint32_t ray_capacity, shade_capacity, surf_capacity;
+    uint32_t ray_capacity, surf_capacity;
 };
 
 // cam and q point to DEVICE copies of the structs
-void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, double* film,
-                    hipStream_t s);
-void launch_trace(const DScene& sc, const Queues& q, uint32_t n, int mode, bool mesh_only, double* film, hipStream_t s);
-void launch_shade(const DScene& sc, const PassDesc& pass, const Queues& q, uint32_t n_upper, double* film, hipStream_t s);
+void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
+                    double* film, hipStream_t s);
+// traces rays[in][0 .. n) and appends their children to rays[1 - in]
+void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, uint32_t n, int mode, bool mesh_only, double* film,
+                  hipStream_t s);
 void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode, double* film, hipStream_t s);
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s);
 // src and dst: packed dx*dy RGBA8 device images; tmp: dx*dy*3 float64

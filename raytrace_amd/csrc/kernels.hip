@@ -3,11 +3,11 @@
 //   k_primary   renderPixel for the samples of a pass; the lanes of a wave share a pixel (or a few) and
 //               take different samples of it: camera ray -> closest hit -> misses counted, hits on
 //               emitting-only materials (Emitter, DebugUV, DebugNormal) summed over the pixel's lanes
-//               and added to the film once; every other hit is appended (wave64 ballot compaction)
-//               to the shade queue
+//               and added to the film once
+//               and, for the other materials, Material.Resolve right away: scattered children appended
+//               (wave64 ballot compaction) to the next generation's ray queue, lit surface points to
+//               the light loop's queue
 //   k_trace     the same for a queued generation of scattered rays, one ray per thread
-//   k_shade     Material.Resolve for the shade queue: children appended to the ray queue,
-//               lit surface points appended for the light loop
 //   k_direct    one thread per (surface point, light): occlusion ray + BRDF, added to the film
 //   k_resolve   film sums -> 8-bit RGBA exactly as renderPixel quantises (render.go:218-224)
 #include "kernels.h"
@@ -321,20 +321,73 @@ struct PathState {
     uint32_t pixel, sample, path, depth_n;
 };
 
-RT_DEV void put_shade(const Queues& q, uint32_t slot, const Ray& r, const PathState& ps, const SceneHit& h) {
-    q.shade_ray.o[0][slot] = r.o.x; q.shade_ray.o[1][slot] = r.o.y; q.shade_ray.o[2][slot] = r.o.z;
-    q.shade_ray.d[0][slot] = r.d.x; q.shade_ray.d[1][slot] = r.d.y; q.shade_ray.d[2][slot] = r.d.z;
-    q.shade_ray.rad[0][slot] = ps.rad.x; q.shade_ray.rad[1][slot] = ps.rad.y; q.shade_ray.rad[2][slot] = ps.rad.z;
-    q.shade_ray.pixel[slot] = ps.pixel;
-    q.shade_ray.sample[slot] = ps.sample;
-    q.shade_ray.path[slot] = ps.path;
-    q.shade_ray.depth_n[slot] = ps.depth_n;
-    q.shade_hit.node[slot] = h.node;
-    q.shade_hit.prim[slot] = h.prim;
-    q.shade_hit.t[slot] = h.c.t;
-    q.shade_hit.at[0][slot] = h.c.at.x; q.shade_hit.at[1][slot] = h.c.at.y; q.shade_hit.at[2][slot] = h.c.at.z;
-    q.shade_hit.nrm[0][slot] = h.c.normal.x; q.shade_hit.nrm[1][slot] = h.c.normal.y; q.shade_hit.nrm[2][slot] = h.c.normal.z;
-    q.shade_hit.uv[0][slot] = h.c.u; q.shade_hit.uv[1][slot] = h.c.v;
+// The second half of tracePath for the lanes with `live` (render.go:174-183): Material.Resolve on the hit, children
+// appended to the next generation (ballot compaction, one atomic per wave and queue), the surface point appended
+// for ComputeDirectLighting.  Returns the hit's emission, which the caller adds to the film.  Must be reached by
+// all lanes of the wave.
+RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, int out, bool live, const Ray& r, const PathState& ps,
+                       const SceneHit& h) {
+    const RayQ& next = q.rays[out];
+    V3 emission = mk(0, 0, 0);
+    uint32_t n_cut = 0, n_counted = 0;  // children beyond MaxRayDepth or invalid: counted, never traced
+    bool want_surf = false, child_ok[2] = {false, false};
+    Scatter sct;
+    V3 at = mk(0, 0, 0), s_n = mk(0, 0, 0), s_wo = mk(0, 0, 0), s_alb = mk(0, 0, 0);
+    uint32_t depth = 0;
+    int mat_index = 0, inside = 0;
+    if (live) {
+        depth = ps.depth_n >> 24;
+        mat_index = sc.nodes[h.node].material;
+        const rt_material m = sc.materials[mat_index];
+        const Col& c = h.c;
+        at = c.at;
+        const uint32_t x = ps.pixel % (uint32_t)pass.dx, row = ps.pixel / (uint32_t)pass.dx;
+        Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(pass.dy - 1 - (int)row) * (uint32_t)pass.dx + x, ps.sample, ps.path, ps.depth_n & 0xFFFFFFu};
+        resolve(sc, m, r.d, ps.rad, c, rng, sct);
+        emission = sct.emission;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (k >= sct.n) continue;
+            if (bad3(c.at) || bad3(sct.dir[k])) { n_counted++; continue; }            // render.go:147-150
+            if ((int)depth + 1 > pass.max_depth) { n_counted++; n_cut++; continue; }  // render.go:151-154
+            child_ok[k] = true;
+        }
+        if (sc.n_lights > 0 && (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC)) {
+            want_surf = true;
+            s_n = unit(c.normal);
+            s_wo = unit(r.d * -1.0);  // s.outgoing.Unit() (material_metal.go:59)
+            if (m.kind == RT_MAT_LAMBERTIAN) s_alb = texture_at(sc, m.texture, c.u, c.v);
+            else if (m.kind == RT_MAT_METAL) s_alb = ld3(m.albedo);
+            else if (!(dot(s_wo, s_n) > 0)) { inside = 1; s_n = s_n * -1.0; }  // material_dielectric.go:112-120
+        }
+    }
+    wave_tally(q.counters, n_counted, 0, n_cut);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const bool want = child_ok[k];
+        const uint32_t slot = wave_append(&q.counters->next_count, want);
+        if (want && slot < q.ray_capacity) {
+            next.o[0][slot] = at.x; next.o[1][slot] = at.y; next.o[2][slot] = at.z;
+            next.d[0][slot] = sct.dir[k].x; next.d[1][slot] = sct.dir[k].y; next.d[2][slot] = sct.dir[k].z;
+            next.rad[0][slot] = sct.rad[k].x; next.rad[1][slot] = sct.rad[k].y; next.rad[2][slot] = sct.rad[k].z;
+            next.pixel[slot] = ps.pixel;
+            next.sample[slot] = ps.sample;
+            next.path[slot] = ps.path * 2u + (uint32_t)k;
+            next.depth_n[slot] = (depth + 1u) << 24;
+        }
+    }
+    const uint32_t ss = wave_append(&q.counters->surf_count, want_surf);
+    if (want_surf && ss < q.surf_capacity) {
+        q.surfs.p[0][ss] = at.x; q.surfs.p[1][ss] = at.y; q.surfs.p[2][ss] = at.z;
+        q.surfs.n[0][ss] = s_n.x; q.surfs.n[1][ss] = s_n.y; q.surfs.n[2][ss] = s_n.z;
+        q.surfs.wo[0][ss] = s_wo.x; q.surfs.wo[1][ss] = s_wo.y; q.surfs.wo[2][ss] = s_wo.z;
+        q.surfs.albedo[0][ss] = s_alb.x; q.surfs.albedo[1][ss] = s_alb.y; q.surfs.albedo[2][ss] = s_alb.z;
+        q.surfs.pixel[ss] = ps.pixel;
+        q.surfs.node[ss] = h.node;
+        q.surfs.material[ss] = mat_index;
+        q.surfs.inside[ss] = inside;
+    }
+    return emission;
 }
 
 // The first half of tracePath for one ray (render.go:143-173): NaN guard, closest hit, miss.
@@ -376,7 +429,9 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // so the rays an XCD has in flight share BVH nodes in its L2, and a wave whose own queue is empty takes items from
 // the other XCDs' queues.  The queue cursors only grow, so every wave reaches the exit after finding all eight
 // queues exhausted.
-template <int MODE, bool MESH_ONLY>
+// SHADE = false: the host has checked that every material only emits, so no hit ever needs Material.Resolve and
+// its code (and registers) is left out.
+template <int MODE, bool MESH_ONLY, bool SHADE>
 __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
     // The camera and the queue descriptors are read through pointers where they are used: as by-value arguments
     // their ~100 dwords would sit in SGPRs for the whole kernel and push other scalars out into VGPR lanes.
@@ -475,8 +530,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
                     ps.path = 1;
                     ps.depth_n = rng.n;
                 }
-                const uint32_t slot = wave_append(&counters->shade_count, want);
-                if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
+                if (SHADE) acc = acc + shade_lane(sc, pass, q, 0, want, r, ps, h);
             }
             // sum over the lanes of a pixel (they are adjacent: xor-shuffles below lanes_s stay inside the pixel)
             for (int off = lanes_s >> 1; off > 0; off >>= 1) {
@@ -497,115 +551,31 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
 }
 
 template <int MODE, bool MESH_ONLY>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_trace(DScene sc, Queues q, uint32_t n, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_trace(DScene sc, PassDesc pass, Queues q, int in, uint32_t n, double* __restrict__ film) {
     const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = i < n;
+    const RayQ& rays = q.rays[in];
     bool want = false;
     uint32_t n_left = 0;
     Ray r;
     SceneHit h;
     PathState ps;
     if (live) {
-        r.o = mk(q.rays.o[0][i], q.rays.o[1][i], q.rays.o[2][i]);
-        r.d = mk(q.rays.d[0][i], q.rays.d[1][i], q.rays.d[2][i]);
-        ps.rad = mk(q.rays.rad[0][i], q.rays.rad[1][i], q.rays.rad[2][i]);
-        ps.pixel = q.rays.pixel[i];
-        ps.sample = q.rays.sample[i];
-        ps.path = q.rays.path[i];
-        ps.depth_n = q.rays.depth_n[i];
+        r.o = mk(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
+        r.d = mk(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
+        ps.rad = mk(rays.rad[0][i], rays.rad[1][i], rays.rad[2][i]);
+        ps.pixel = rays.pixel[i];
+        ps.sample = rays.sample[i];
+        ps.path = rays.path[i];
+        ps.depth_n = rays.depth_n[i];
         V3 em;
         const int what = trace_one<MODE, MESH_ONLY>(sc, r, ps.rad, h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
         if (what == 1) film_add(film, ps.pixel, em);
         want = what == 2;
     }
-    const uint32_t slot = wave_append(&q.counters->shade_count, want);
-    if (want && slot < q.shade_capacity) put_shade(q, slot, r, ps, h);
+    const V3 em2 = shade_lane(sc, pass, q, 1 - in, want, r, ps, h);
+    if (want) film_add(film, ps.pixel, em2);
     wave_tally(q.counters, live ? 1u : 0u, n_left, 0);
-}
-
-// The second half of tracePath (render.go:174-182) for hits that need it: Material.Resolve,
-// children appended to the ray queue, lit points appended for k_direct.
-__global__ void __launch_bounds__(kBlock) k_shade(DScene sc, PassDesc pass, Queues q, double* __restrict__ film) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t n = min(q.counters->shade_count, q.shade_capacity);
-    if (blockIdx.x * kBlock >= n) return;  // whole block beyond the queue (the grid is an upper bound)
-    const bool live = i < n;
-    int n_child = 0;
-    uint32_t n_cut = 0, n_counted = 0;  // children beyond MaxRayDepth or invalid: counted, never traced
-    bool want_surf = false;
-    V3 child_d[2], child_rad[2];
-    uint32_t child_path[2];
-    V3 at = mk(0, 0, 0), s_n = mk(0, 0, 0), s_wo = mk(0, 0, 0), s_alb = mk(0, 0, 0);
-    uint32_t pixel = 0, sample = 0, depth = 0;
-    int node = 0, mat_index = 0, inside = 0;
-    if (live) {
-        const Ray r{mk(q.shade_ray.o[0][i], q.shade_ray.o[1][i], q.shade_ray.o[2][i]),
-                    mk(q.shade_ray.d[0][i], q.shade_ray.d[1][i], q.shade_ray.d[2][i])};
-        const V3 rad = mk(q.shade_ray.rad[0][i], q.shade_ray.rad[1][i], q.shade_ray.rad[2][i]);
-        pixel = q.shade_ray.pixel[i];
-        sample = q.shade_ray.sample[i];
-        const uint32_t path = q.shade_ray.path[i];
-        const uint32_t depth_n = q.shade_ray.depth_n[i];
-        depth = depth_n >> 24;
-        node = q.shade_hit.node[i];
-        mat_index = sc.nodes[node].material;
-        const rt_material m = sc.materials[mat_index];
-        Col c;
-        c.t = q.shade_hit.t[i];
-        c.at = mk(q.shade_hit.at[0][i], q.shade_hit.at[1][i], q.shade_hit.at[2][i]);
-        c.normal = mk(q.shade_hit.nrm[0][i], q.shade_hit.nrm[1][i], q.shade_hit.nrm[2][i]);
-        c.u = q.shade_hit.uv[0][i];
-        c.v = q.shade_hit.uv[1][i];
-        at = c.at;
-        const uint32_t x = pixel % (uint32_t)pass.dx, row = pixel / (uint32_t)pass.dx;
-        Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(pass.dy - 1 - (int)row) * (uint32_t)pass.dx + x, sample, path, depth_n & 0xFFFFFFu};
-        Scatter sct;
-        resolve(sc, m, r.d, rad, c, rng, sct);
-        film_add(film, pixel, sct.emission);
-        for (int k = 0; k < sct.n; k++) {
-            if (bad3(c.at) || bad3(sct.dir[k])) { n_counted++; continue; }                      // render.go:147-150
-            if ((int)depth + 1 > pass.max_depth) { n_counted++; n_cut++; continue; }            // render.go:151-154
-            child_d[n_child] = sct.dir[k];
-            child_rad[n_child] = sct.rad[k];
-            child_path[n_child] = path * 2u + (uint32_t)k;
-            n_child++;
-        }
-        if (sc.n_lights > 0 && (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC)) {
-            want_surf = true;
-            s_n = unit(c.normal);
-            s_wo = unit(r.d * -1.0);  // s.outgoing.Unit() (material_metal.go:59)
-            if (m.kind == RT_MAT_LAMBERTIAN) s_alb = texture_at(sc, m.texture, c.u, c.v);
-            else if (m.kind == RT_MAT_METAL) s_alb = ld3(m.albedo);
-            else if (!(dot(s_wo, s_n) > 0)) { inside = 1; s_n = s_n * -1.0; }  // material_dielectric.go:112-120
-        }
-    }
-    wave_tally(q.counters, n_counted, 0, n_cut);
-    // wave64 ballot compaction of the surviving paths into the next generation
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const bool want = n_child > k;
-        const uint32_t slot = wave_append(&q.counters->next_count, want);
-        if (want && slot < q.ray_capacity) {
-            q.rays.o[0][slot] = at.x; q.rays.o[1][slot] = at.y; q.rays.o[2][slot] = at.z;
-            q.rays.d[0][slot] = child_d[k].x; q.rays.d[1][slot] = child_d[k].y; q.rays.d[2][slot] = child_d[k].z;
-            q.rays.rad[0][slot] = child_rad[k].x; q.rays.rad[1][slot] = child_rad[k].y; q.rays.rad[2][slot] = child_rad[k].z;
-            q.rays.pixel[slot] = pixel;
-            q.rays.sample[slot] = sample;
-            q.rays.path[slot] = child_path[k];
-            q.rays.depth_n[slot] = (depth + 1u) << 24;
-        }
-    }
-    const uint32_t ss = wave_append(&q.counters->surf_count, want_surf);
-    if (want_surf && ss < q.surf_capacity) {
-        q.surfs.p[0][ss] = at.x; q.surfs.p[1][ss] = at.y; q.surfs.p[2][ss] = at.z;
-        q.surfs.n[0][ss] = s_n.x; q.surfs.n[1][ss] = s_n.y; q.surfs.n[2][ss] = s_n.z;
-        q.surfs.wo[0][ss] = s_wo.x; q.surfs.wo[1][ss] = s_wo.y; q.surfs.wo[2][ss] = s_wo.z;
-        q.surfs.albedo[0][ss] = s_alb.x; q.surfs.albedo[1][ss] = s_alb.y; q.surfs.albedo[2][ss] = s_alb.z;
-        q.surfs.pixel[ss] = pixel;
-        q.surfs.node[ss] = node;
-        q.surfs.material[ss] = mat_index;
-        q.surfs.inside[ss] = inside;
-    }
 }
 
 // ComputeDirectLighting's loop body for one (surface point, light) pair
@@ -740,8 +710,8 @@ static unsigned persistent_grid(K kernel, size_t lds) {
     return cached_grid;
 }
 
-void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, double* film,
-                    hipStream_t s) {
+void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
+                    double* film, hipStream_t s) {
     if (pass.n_pixels <= 0) return;
     const size_t lds = stack_bytes(sc, mode);
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
@@ -750,31 +720,27 @@ void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, 
         const dim3 grid(std::min(resident, (tiles + 7u) & ~7u)), block(kTraceBlock);
         hipLaunchKernelGGL(kernel, grid, block, lds, s, sc, cam, pass, q, film);
     };
-    if (mode == RT_MODE_REFERENCE) {
-        if (mesh_only) go(k_primary<RT_MODE_REFERENCE, true>);
-        else go(k_primary<RT_MODE_REFERENCE, false>);
-    } else {
-        if (mesh_only) go(k_primary<RT_MODE_FAST, true>);
-        else go(k_primary<RT_MODE_FAST, false>);
-    }
+    auto pick = [&](auto mode_tag) {
+        constexpr int M = decltype(mode_tag)::value;
+        if (mesh_only) { if (shade) go(k_primary<M, true, true>); else go(k_primary<M, true, false>); }
+        else           { if (shade) go(k_primary<M, false, true>); else go(k_primary<M, false, false>); }
+    };
+    if (mode == RT_MODE_REFERENCE) pick(std::integral_constant<int, RT_MODE_REFERENCE>{});
+    else pick(std::integral_constant<int, RT_MODE_FAST>{});
 }
 
-void launch_trace(const DScene& sc, const Queues& q, uint32_t n, int mode, bool mesh_only, double* film, hipStream_t s) {
+void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, uint32_t n, int mode, bool mesh_only, double* film,
+                  hipStream_t s) {
     if (n == 0) return;
     const dim3 grid(trace_blocks(n)), block(kTraceBlock);
     const size_t lds = stack_bytes(sc, mode);
     if (mode == RT_MODE_REFERENCE) {
-        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true>), grid, block, lds, s, sc, q, n, film);
-        else hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, false>), grid, block, lds, s, sc, q, n, film);
+        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true>), grid, block, lds, s, sc, pass, q, in, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, false>), grid, block, lds, s, sc, pass, q, in, n, film);
     } else {
-        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, true>), grid, block, lds, s, sc, q, n, film);
-        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false>), grid, block, lds, s, sc, q, n, film);
+        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, true>), grid, block, lds, s, sc, pass, q, in, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false>), grid, block, lds, s, sc, pass, q, in, n, film);
     }
-}
-
-void launch_shade(const DScene& sc, const PassDesc& pass, const Queues& q, uint32_t n_upper, double* film, hipStream_t s) {
-    if (n_upper == 0) return;
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(n_upper)), dim3(kBlock), 0, s, sc, pass, q, film);
 }
 
 void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode, double* film, hipStream_t s) {

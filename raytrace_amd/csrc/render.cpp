@@ -73,15 +73,6 @@ void carve(RayQ& r, void* base, size_t cap) {
     r.path = reinterpret_cast<uint32_t*>(p); p += cap * 4;
     r.depth_n = reinterpret_cast<uint32_t*>(p);
 }
-void carve(HitQ& h, void* base, size_t cap) {
-    char* p = static_cast<char*>(base);
-    h.t = reinterpret_cast<double*>(p); p += cap * 8;
-    for (int k = 0; k < 3; k++) { h.at[k] = reinterpret_cast<double*>(p); p += cap * 8; }
-    for (int k = 0; k < 3; k++) { h.nrm[k] = reinterpret_cast<double*>(p); p += cap * 8; }
-    for (int k = 0; k < 2; k++) { h.uv[k] = reinterpret_cast<double*>(p); p += cap * 8; }
-    h.node = reinterpret_cast<int32_t*>(p); p += cap * 4;
-    h.prim = reinterpret_cast<int32_t*>(p);
-}
 void carve(SurfQ& s, void* base, size_t cap) {
     char* p = static_cast<char*>(base);
     for (int k = 0; k < 3; k++) { s.p[k] = reinterpret_cast<double*>(p); p += cap * 8; }
@@ -114,20 +105,18 @@ int ensure_work(rt_scene* sc) {
     w->q = (uint32_t)env_size("RT_QUEUE_RAYS", (size_t)1 << 25);
     if (w->q < 64 * 64) w->q = 64 * 64;
     const size_t q = w->q;
-    char *rays = nullptr, *sray = nullptr, *shit = nullptr, *surfs = nullptr;
+    char *rays0 = nullptr, *rays1 = nullptr, *surfs = nullptr;
     // a scene that never shades needs none of the queues (kernels still get valid pointers)
     const size_t qq = sc->all_terminal ? 64 : q;
-    HIP_TRY(w->mem.alloc(2 * qq * kRayBytes, &rays));
-    HIP_TRY(w->mem.alloc(qq * kRayBytes, &sray));
-    HIP_TRY(w->mem.alloc(qq * kHitBytes, &shit));
+    // a launch traces at most q rays and each of them scatters at most two children
+    HIP_TRY(w->mem.alloc(2 * qq * kRayBytes, &rays0));
+    HIP_TRY(w->mem.alloc(2 * qq * kRayBytes, &rays1));
     HIP_TRY(w->mem.alloc(qq * kSurfBytes, &surfs));
     HIP_TRY(w->mem.alloc(1, &w->queues.counters));
-    carve(w->queues.rays, rays, 2 * qq);
-    carve(w->queues.shade_ray, sray, qq);
-    carve(w->queues.shade_hit, shit, qq);
+    carve(w->queues.rays[0], rays0, 2 * qq);
+    carve(w->queues.rays[1], rays1, 2 * qq);
     carve(w->queues.surfs, surfs, qq);
     w->queues.ray_capacity = (uint32_t)(2 * qq);
-    w->queues.shade_capacity = (uint32_t)qq;
     w->queues.surf_capacity = (uint32_t)qq;
     HIP_TRY(w->mem.alloc(1, &w->d_queues));
     HIP_TRY(w->mem.alloc(1, &w->d_camera));
@@ -274,7 +263,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     const int64_t tiles_total = (int64_t)pass.groups_x * ((local_rows + 63) / 64) * 64;  // whole groups; tiles outside the image idle
     const int s_first = o->sample_count > 0 ? o->sample_begin : 0;
     const int s_end = o->sample_count > 0 ? o->sample_begin + o->sample_count : o->rays_per_pixel;
-    // paths per primary launch: bounded by the shade queue unless nothing is ever queued
+    // paths per primary launch: bounded by the queues (two children and one surface point per path) unless nothing is ever queued
     const int64_t paths_per_launch = sc->all_terminal ? ((int64_t)1 << 40) : (int64_t)w.q;
 
     HIP_TRY(hipMemsetAsync(q.counters, 0, sizeof(Counters), stream));
@@ -290,7 +279,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         return RT_OK;
     };
     auto reset_cursors = [&]() -> int {  // zero the append and tile cursors, keep the statistics
-        HIP_TRY(hipMemsetAsync(&q.counters->shade_count, 0, sizeof(Counters) - offsetof(Counters, shade_count), stream));
+        HIP_TRY(hipMemsetAsync(&q.counters->next_count, 0, sizeof(Counters) - offsetof(Counters, next_count), stream));
         return RT_OK;
     };
 
@@ -361,7 +350,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             EventPair* ev = nullptr;
             HIP_TRY(events.next(&ev));
             HIP_TRY(hipEventRecord(ev->a, stream));
-            launch_primary(sc->dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, film, stream);
+            launch_primary(sc->dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream);
             HIP_TRY(hipEventRecord(ev->b, stream));
             HIP_TRY(hipGetLastError());
             traverse_launches++;
@@ -372,18 +361,15 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                 }
                 continue;
             }
-            // generations of scattered rays
-            uint32_t n_traced = (uint32_t)std::min<int64_t>(pass.n_pixels * s_count, q.shade_capacity);
+            // generations of scattered rays: the launch just queued left its children in rays[cur]
+            int cur = 0;
             for (;;) {
                 if (sc->cancel.load()) {
                     (void)hipStreamSynchronize(stream);
                     return fail(RT_ERR_CANCELLED, "render cancelled");
                 }
-                launch_shade(sc->dev, pass, q, n_traced, film, stream);  // grid = upper bound; the kernel reads the real count
-                HIP_TRY(hipGetLastError());
                 if (int rc = read_counters()) return rc;
-                if (host.shade_count > q.shade_capacity || host.next_count > q.ray_capacity || host.surf_count > q.surf_capacity)
-                    return fail(RT_ERR_DEVICE, "internal queue overflow");
+                if (host.next_count > q.ray_capacity || host.surf_count > q.surf_capacity) return fail(RT_ERR_DEVICE, "internal queue overflow");
                 if (host.surf_count > 0) {
                     launch_direct(sc->dev, q, host.surf_count, o->mode, film, stream);
                     HIP_TRY(hipGetLastError());
@@ -399,25 +385,25 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                         w.pool_capacity = want;
                     }
                     if (pool_top + excess > w.pool_capacity) return fail(RT_ERR_NOMEM, "ray pool exhausted");
-                    HIP_TRY(copy_rays(w.pool, pool_top, q.rays, w.q, excess, stream));
+                    HIP_TRY(copy_rays(w.pool, pool_top, q.rays[cur], w.q, excess, stream));
                     pool_top += excess;
                     n = w.q;
                 }
                 if (n == 0) {
                     if (pool_top == 0) break;
                     const uint64_t take = std::min<uint64_t>(pool_top, w.q);
-                    HIP_TRY(copy_rays(q.rays, 0, w.pool, pool_top - take, take, stream));
+                    HIP_TRY(copy_rays(q.rays[cur], 0, w.pool, pool_top - take, take, stream));
                     pool_top -= take;
                     n = (uint32_t)take;
                 }
                 if (int rc = reset_cursors()) return rc;
                 HIP_TRY(events.next(&ev));
                 HIP_TRY(hipEventRecord(ev->a, stream));
-                launch_trace(sc->dev, q, n, o->mode, sc->mesh_only, film, stream);
+                launch_trace(sc->dev, pass, q, cur, n, o->mode, sc->mesh_only, film, stream);
                 HIP_TRY(hipEventRecord(ev->b, stream));
                 HIP_TRY(hipGetLastError());
                 traverse_launches++;
-                n_traced = n;
+                cur = 1 - cur;
             }
         }
         if (pilot) {

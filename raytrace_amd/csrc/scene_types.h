@@ -121,17 +121,6 @@ struct RayQ {
 };
 constexpr size_t kRayBytes = 9 * 8 + 4 * 4;
 
-// Collisions (shape.go:11-16) plus which node / face, same index as the ray they belong to.
-struct HitQ {
-    int32_t* node;
-    int32_t* prim;
-    double* t;
-    double* at[3];
-    double* nrm[3];
-    double* uv[2];
-};
-constexpr size_t kHitBytes = 2 * 4 + 9 * 8;
-
 // Lit surface points waiting for their light loop (material_*.go ComputeDirectLighting).
 struct SurfQ {
     double* p[3];
@@ -147,8 +136,7 @@ constexpr size_t kSurfBytes = 12 * 8 + 4 * 4;
 
 struct Counters {
     unsigned long long total, exceeded, left, shadow;  // RenderStats (render.go:38-45) + occlusion rays
-    unsigned int shade_count, next_count, surf_count;  // append cursors of the three queues
-    unsigned int pad;
+    unsigned int next_count, surf_count;  // append cursors of the next generation's rays and of the lit surface points
     unsigned int tile_cursor[8];  // next tile of each XCD's share of a primary launch
 };
 
