@@ -289,8 +289,9 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
                 const V3 p0 = ld3(p), p1 = ld3(p + 3), p2 = ld3(p + 6);
                 double t, u, v;
                 if (mt_core(r, p0, p1, p2, 1e-8, tmin, tmax, t, u, v)) {
-                    hit = true;
                     if (ANY_HIT) return true;
+                    if (hit && t == t_out && first + q < prim) continue;  // equal distances: see mesh_collide_packet
+                    hit = true;
                     tmax = t;
                     tmax32 = up32(t - f.t_shift);
                     prim = first + q;
@@ -305,6 +306,114 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
             st.pop(ref, tnear);
             if (tnear <= tmax32) { cur = ref; break; }
         }
+    }
+    return hit;
+}
+
+// The same search for a whole wave at once: one traversal, shared by all active lanes, visits every node that the
+// ray of at least one lane can reach.  The current node, the stack depth and every branch of the walk are wave-uniform,
+// so nodes and float32 faces always come through the scalar cache into SGPRs, the walk's control flow is scalar
+// branches instead of per-lane masks, and lanes never drift apart.  It pays when the rays of the wave are close together
+// (the samples of one pixel, or of neighbouring pixels): the union of their walks is then hardly longer than each one.
+// Results per lane are those of mesh_collide_fast up to the choice among faces hit at exactly the same distance.
+//
+// Per lane: cur_tn is the entry distance of its ray into the current node (+inf when it misses the node's box; the
+// lane then only follows along) and tmax32 its current search limit.  The stack (one pair per tree level: near-first
+// descent) holds the wave-uniform child reference and each lane's own entry distance.
+// Must be entered by the lanes of a wave together (any subset); each lane gets its own ray's answer.
+template <bool ANY_HIT>
+RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, double tmin, double tmax, int& prim, double& t_out,
+                                double& u_out, double& v_out, int32_t* lds, int stride, int cap, VisitCounts& cnt) {
+    FastRay f;
+    const bool alive = fast_setup(m, r, tmin, tmax, f);
+    if (__builtin_amdgcn_ballot_w64(alive) == 0) return false;
+    const FastNode* nodes = sc.fast_nodes + m.fast_off;
+    const double* pos = sc.prim_pos + m.prim_off * 9;
+    const Tri32* tri32 = sc.prim_tri32 + m.prim_off;
+    const float inf32 = __builtin_inff();
+    const float tmin32 = alive ? fmaxf(0.0f, (float)(tmin - f.t_shift)) : inf32;
+    float tmax32 = alive ? up32(tmax - f.t_shift) : -1.0f;  // a lane whose ray misses the root box fails every test below
+    const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
+    const float dlen = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float err_d = kErr * dlen, err_r = err_d * m.radius;
+    constexpr int32_t kDone = kFastEmpty;
+    int32_t cur = 0;  // wave-uniform
+    int sp = 0;       // wave-uniform
+    float cur_tn = tmin32;
+    bool hit = false;
+    for (;;) {
+        if (cur >= 0) {  // inner node: test both children; go to the one most lanes reach first, push the other
+            const FastNode n = load_node_scalar(nodes, cur);
+            cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
+            float tn[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][0], n.b[k][0][1]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
+                const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][0], n.b[k][1][1]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
+                const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][0], n.b[k][2][1]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
+                const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), tmin32));
+                const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), tmax32));
+                tn[k] = (tnear <= tfar) ? tnear : inf32;
+            }
+            const bool go0 = tn[0] < inf32, go1 = tn[1] < inf32;
+            const unsigned long long m0 = n.child[0] != kFastEmpty ? __builtin_amdgcn_ballot_w64(go0) : 0ull;
+            const unsigned long long m1 = n.child[1] != kFastEmpty ? __builtin_amdgcn_ballot_w64(go1) : 0ull;
+            if (m0 != 0 && m1 != 0) {
+                const unsigned long long first1 = __builtin_amdgcn_ballot_w64(tn[1] < tn[0]);  // lanes that reach child 1 first
+                const bool swap = 2 * __popcll(first1) > __popcll(m0 | m1);
+                if (sp < cap) {
+                    lds[(2 * sp) * stride] = swap ? n.child[0] : n.child[1];
+                    lds[(2 * sp + 1) * stride] = __float_as_int(swap ? tn[0] : tn[1]);
+                    sp++;
+                }
+                cur = swap ? n.child[1] : n.child[0];
+                cur_tn = swap ? tn[1] : tn[0];
+                continue;
+            }
+            if ((m0 | m1) != 0) {
+                cur = m1 != 0 ? n.child[1] : n.child[0];
+                cur_tn = m1 != 0 ? tn[1] : tn[0];
+                continue;
+            }
+        } else {  // leaf
+            const uint32_t code = (uint32_t)~cur;
+            const int32_t first = (int32_t)(code >> 3);
+            const int32_t count = (int32_t)(code & 7u) + 1;
+            for (int32_t q = 0; q < count; q++) {
+                const Tri32 t32 = load_tri32_scalar(tri32, first + q);
+                const bool maybe = cur_tn <= tmax32 && !tri32_rejects(t32, f, dx, dy, dz, err_r, err_d);
+                if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+                if (maybe) {
+                    cnt.prims++;
+                    const double* p = pos + (int64_t)(first + q) * 9;
+                    const V3 p0 = ld3(p), p1 = ld3(p + 3), p2 = ld3(p + 6);
+                    double t, u, v;
+                    // Among faces hit at exactly the same distance the one latest in leaf order wins, whatever the order of
+                    // the walk: that is the face the reference's left-first walk keeps (shape_bvh.go:53-72: the right subtree wins
+                    // unless the left hit is strictly nearer; shape_mesh.go:122 accepts t == tmax), and it makes a ray's answer independent of its wave.
+                    if (mt_core(r, p0, p1, p2, 1e-8, tmin, tmax, t, u, v) && !(hit && t == t_out && first + q < prim)) {
+                        hit = true;
+                        tmax = t;
+                        tmax32 = ANY_HIT ? -1.0f : up32(t - f.t_shift);  // any hit: this lane is finished
+                        prim = first + q;
+                        t_out = t; u_out = u; v_out = v;
+                    }
+                }
+            }
+            if (ANY_HIT && __builtin_amdgcn_ballot_w64(tmax32 >= 0.0f) == 0) break;
+        }
+        cur = kDone;
+        while (sp > 0) {  // pop, skipping subtrees that begin beyond every lane's current hit
+            sp--;
+            const int32_t ref = lds[(2 * sp) * stride];
+            const float tnear = __int_as_float(lds[(2 * sp + 1) * stride]);
+            if (__builtin_amdgcn_ballot_w64(tnear <= tmax32) != 0) {
+                cur = __builtin_amdgcn_readfirstlane(ref);
+                cur_tn = tnear;
+                break;
+            }
+        }
+        if (cur == kDone) break;
     }
     return hit;
 }

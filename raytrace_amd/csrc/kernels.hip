@@ -141,7 +141,8 @@ RT_DEV bool node_box_reachable(const double* b, const Ray& r, V3 inv, double tmi
 
 // The node loop of tracePath (render.go:155-169).  MESH_ONLY: the host has checked that every
 // node is a plain mesh, so the other shapes' code (and its registers) is left out.
-template <int MODE, bool MESH_ONLY = false>
+// PACKET (fast mode, mesh-only scenes): the lanes of the wave trace neighbouring rays and walk each mesh together.
+template <int MODE, bool MESH_ONLY = false, bool PACKET = false>
 RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, LdsStack ls) {
     double min_dist = tmax;
     bool hit = false;
@@ -157,6 +158,7 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
             int p = 0;
             bool got;
             if (MODE == RT_MODE_REFERENCE) got = mesh_collide_ref(sc, m, r, tmin, min_dist, p, t, u, v, cnt);
+            else if (PACKET) got = mesh_collide_packet<false>(sc, m, r, tmin, min_dist, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt);
             else got = mesh_collide_fast<false>(sc, m, r, tmin, min_dist, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt);
             if (got && t < min_dist) {
                 min_dist = t;
@@ -393,11 +395,11 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
 // The first half of tracePath for one ray (render.go:143-173): NaN guard, closest hit, miss.
 // Returns 0 = nothing further (invalid ray or miss), 1 = hit an emitting-only material
 // (`emission` set), 2 = hit needs Material.Resolve (`h` set).
-template <int MODE, bool MESH_ONLY>
+template <int MODE, bool MESH_ONLY, bool PACKET = false>
 RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, uint32_t& n_left, LdsStack ls) {
     if (bad3(r.o) || bad3(r.d)) return 0;  // render.go:147-150
     VisitCounts cnt{0, 0};
-    if (!scene_closest<MODE, MESH_ONLY>(sc, r, kEps, kMaxFloat, h, cnt, ls)) {
+    if (!scene_closest<MODE, MESH_ONLY, PACKET>(sc, r, kEps, kMaxFloat, h, cnt, ls)) {
         n_left++;
         return 0;
     }
@@ -521,7 +523,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
                     r = camera_cast(cam, fs, ft, rng);
                     n_total++;
                     V3 em;
-                    const int what = trace_one<MODE, MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
+                    const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST && MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
                     if (what == 1) acc = acc + em;
                     want = what == 2;
                     ps.rad = mk(1, 1, 1);
