@@ -318,8 +318,9 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
 // Results per lane are those of mesh_collide_fast up to the choice among faces hit at exactly the same distance.
 //
 // Per lane: cur_tn is the entry distance of its ray into the current node (+inf when it misses the node's box; the
-// lane then only follows along) and tmax32 its current search limit.  The stack (one pair per tree level: near-first
-// descent) holds the wave-uniform child reference and each lane's own entry distance.
+// lane then only follows along) and tmax32 its current search limit.  The stack (one entry per tree level: near-first
+// descent) holds each lane's own entry distance, lds[level * stride], and after those cap rows the child references,
+// one per level and wave since they are wave-uniform.
 // Must be entered by the lanes of a wave together (any subset); each lane gets its own ray's answer.
 template <bool ANY_HIT>
 RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, double tmin, double tmax, int& prim, double& t_out,
@@ -337,6 +338,7 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
     const float dlen = sqrtf(dx * dx + dy * dy + dz * dz);
     const float err_d = kErr * dlen, err_r = err_d * m.radius;
     constexpr int32_t kDone = kFastEmpty;
+    int32_t* const refs = lds - (int)threadIdx.x + cap * stride + (int)(threadIdx.x >> 6) * cap;
     int32_t cur = 0;  // wave-uniform
     int sp = 0;       // wave-uniform
     float cur_tn = tmin32;
@@ -362,8 +364,8 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
                 const unsigned long long first1 = __builtin_amdgcn_ballot_w64(tn[1] < tn[0]);  // lanes that reach child 1 first
                 const bool swap = 2 * __popcll(first1) > __popcll(m0 | m1);
                 if (sp < cap) {
-                    lds[(2 * sp) * stride] = swap ? n.child[0] : n.child[1];
-                    lds[(2 * sp + 1) * stride] = __float_as_int(swap ? tn[0] : tn[1]);
+                    refs[sp] = swap ? n.child[0] : n.child[1];  // every lane stores the same value
+                    lds[sp * stride] = __float_as_int(swap ? tn[0] : tn[1]);
                     sp++;
                 }
                 cur = swap ? n.child[1] : n.child[0];
@@ -405,10 +407,9 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
         cur = kDone;
         while (sp > 0) {  // pop, skipping subtrees that begin beyond every lane's current hit
             sp--;
-            const int32_t ref = lds[(2 * sp) * stride];
-            const float tnear = __int_as_float(lds[(2 * sp + 1) * stride]);
+            const float tnear = __int_as_float(lds[sp * stride]);
             if (__builtin_amdgcn_ballot_w64(tnear <= tmax32) != 0) {
-                cur = __builtin_amdgcn_readfirstlane(ref);
+                cur = __builtin_amdgcn_readfirstlane(refs[sp]);
                 cur_tn = tnear;
                 break;
             }

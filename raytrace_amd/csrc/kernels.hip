@@ -34,6 +34,9 @@ struct LdsStack {
 };
 extern __shared__ int32_t dyn_lds[];
 // Waves per SIMD the traversal kernels are compiled for in fast mode (caps VGPRs at 512 / waves).
+#ifndef RT_PACKET_WAVES
+#define RT_PACKET_WAVES 4  // the same for the primary kernel of mesh-only scenes (wave-packet traversal)
+#endif
 #ifndef RT_FAST_WAVES
 #define RT_FAST_WAVES 3
 #endif
@@ -434,7 +437,7 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // SHADE = false: the host has checked that every material only emits, so no hit ever needs Material.Resolve and
 // its code (and registers) is left out.
 template <int MODE, bool MESH_ONLY, bool SHADE>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY ? RT_PACKET_WAVES : RT_FAST_WAVES) : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
     // The camera and the queue descriptors are read through pointers where they are used: as by-value arguments
     // their ~100 dwords would sit in SGPRs for the whole kernel and push other scalars out into VGPR lanes.
     const DCamera& cam = *camp;
@@ -715,7 +718,9 @@ static unsigned persistent_grid(K kernel, size_t lds) {
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
                     double* film, hipStream_t s) {
     if (pass.n_pixels <= 0) return;
-    const size_t lds = stack_bytes(sc, mode);
+    size_t lds = stack_bytes(sc, mode);
+    // wave-packet traversal: one distance per lane and level, one reference per level
+    if (mode == RT_MODE_FAST && mesh_only) lds = (size_t)sc.stack_pairs * (kTraceBlock + kTraceBlock / 64) * sizeof(int32_t);
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);

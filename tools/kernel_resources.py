@@ -14,7 +14,7 @@ def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + ROOT + "/include",
            "-I" + ROOT + "/raytrace_amd/csrc", "-c", ROOT + "/raytrace_amd/csrc/kernels.hip", "-o", "/tmp/kernel_resources.o",
-           "-Rpass-analysis=kernel-resource-usage"]
+           "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("EXTRA_FLAGS", "").split()
     out = subprocess.run(cmd, capture_output=True, text=True).stderr
     cur = None
     rows = {}
