@@ -310,6 +310,14 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
     return hit;
 }
 
+// Diagnostics of the packet walk (builds with -DRT_VISIT_STATS only): events per wave, summed over the launch.
+#ifdef RT_VISIT_STATS
+__device__ unsigned long long g_packet_stats[16];  // walks, inner nodes, leaves, float32 face tests, float64 face tests, pops, pushes, -, cycles in walks, cycles in rounds, rounds, cycles in leaves
+#define RT_STAT(i, n) do { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&g_packet_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define RT_STAT(i, n) do { } while (0)
+#endif
+
 // The same search for a whole wave at once: one traversal, shared by all active lanes, visits every node that the
 // ray of at least one lane can reach.  The current node, the stack depth and every branch of the walk are wave-uniform,
 // so nodes and float32 faces always come through the scalar cache into SGPRs, the walk's control flow is scalar
@@ -319,8 +327,8 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
 //
 // Per lane: cur_tn is the entry distance of its ray into the current node (+inf when it misses the node's box; the
 // lane then only follows along) and tmax32 its current search limit.  The stack (one entry per tree level: near-first
-// descent) holds each lane's own entry distance, lds[level * stride], and after those cap rows the child references,
-// one per level and wave since they are wave-uniform.
+// descent) holds each lane's own entry distance, lds[level * stride], and after those cap rows (of the wave's 64 lanes)
+// the child references, one per level since they are wave-uniform.
 // Must be entered by the lanes of a wave together (any subset); each lane gets its own ray's answer.
 template <bool ANY_HIT>
 RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, double tmin, double tmax, int& prim, double& t_out,
@@ -328,6 +336,11 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
     FastRay f;
     const bool alive = fast_setup(m, r, tmin, tmax, f);
     if (__builtin_amdgcn_ballot_w64(alive) == 0) return false;
+    RT_STAT(0, 1);
+#ifdef RT_VISIT_STATS
+    const long long walk_t0 = clock64();
+    long long leaf_cycles = 0;
+#endif
     const FastNode* nodes = sc.fast_nodes + m.fast_off;
     const double* pos = sc.prim_pos + m.prim_off * 9;
     const Tri32* tri32 = sc.prim_tri32 + m.prim_off;
@@ -338,7 +351,7 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
     const float dlen = sqrtf(dx * dx + dy * dy + dz * dz);
     const float err_d = kErr * dlen, err_r = err_d * m.radius;
     constexpr int32_t kDone = kFastEmpty;
-    int32_t* const refs = lds - (int)threadIdx.x + cap * stride + (int)(threadIdx.x >> 6) * cap;
+    int32_t* const refs = lds - (int)(threadIdx.x & 63) + cap * stride;  // the wave's own region: cap rows of `stride` = 64 lanes, then the references
     int32_t cur = 0;  // wave-uniform
     int sp = 0;       // wave-uniform
     float cur_tn = tmin32;
@@ -346,6 +359,7 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
     for (;;) {
         if (cur >= 0) {  // inner node: test both children; go to the one most lanes reach first, push the other
             const FastNode n = load_node_scalar(nodes, cur);
+            RT_STAT(1, 1);
             cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
             float tn[2];
 #pragma unroll
@@ -364,6 +378,7 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
                 const unsigned long long first1 = __builtin_amdgcn_ballot_w64(tn[1] < tn[0]);  // lanes that reach child 1 first
                 const bool swap = 2 * __popcll(first1) > __popcll(m0 | m1);
                 if (sp < cap) {
+                    RT_STAT(6, 1);
                     refs[sp] = swap ? n.child[0] : n.child[1];  // every lane stores the same value
                     lds[sp * stride] = __float_as_int(swap ? tn[0] : tn[1]);
                     sp++;
@@ -381,14 +396,21 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
             const uint32_t code = (uint32_t)~cur;
             const int32_t first = (int32_t)(code >> 3);
             const int32_t count = (int32_t)(code & 7u) + 1;
+            RT_STAT(2, 1);
+            RT_STAT(3, count);
+#ifdef RT_VISIT_STATS
+            const long long leaf_t0 = clock64();
+#endif
             for (int32_t q = 0; q < count; q++) {
                 const Tri32 t32 = load_tri32_scalar(tri32, first + q);
                 const bool maybe = cur_tn <= tmax32 && !tri32_rejects(t32, f, dx, dy, dz, err_r, err_d);
                 if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+                RT_STAT(4, 1);
                 if (maybe) {
                     cnt.prims++;
-                    const double* p = pos + (int64_t)(first + q) * 9;
-                    const V3 p0 = ld3(p), p1 = ld3(p + 3), p2 = ld3(p + 6);
+                    // the face is the same for every lane: its vertices come through the scalar cache into SGPRs as well
+                    const RT_CONST_AS double* p = (const RT_CONST_AS double*)(pos + (int64_t)(first + q) * 9);
+                    const V3 p0 = mk(p[0], p[1], p[2]), p1 = mk(p[3], p[4], p[5]), p2 = mk(p[6], p[7], p[8]);
                     double t, u, v;
                     // Among faces hit at exactly the same distance the one latest in leaf order wins, whatever the order of
                     // the walk: that is the face the reference's left-first walk keeps (shape_bvh.go:53-72: the right subtree wins
@@ -402,11 +424,15 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
                     }
                 }
             }
+#ifdef RT_VISIT_STATS
+            leaf_cycles += clock64() - leaf_t0;
+#endif
             if (ANY_HIT && __builtin_amdgcn_ballot_w64(tmax32 >= 0.0f) == 0) break;
         }
         cur = kDone;
         while (sp > 0) {  // pop, skipping subtrees that begin beyond every lane's current hit
             sp--;
+            RT_STAT(5, 1);
             const float tnear = __int_as_float(lds[sp * stride]);
             if (__builtin_amdgcn_ballot_w64(tnear <= tmax32) != 0) {
                 cur = __builtin_amdgcn_readfirstlane(refs[sp]);
@@ -416,6 +442,10 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
         }
         if (cur == kDone) break;
     }
+#ifdef RT_VISIT_STATS
+    RT_STAT(8, clock64() - walk_t0);
+    RT_STAT(11, leaf_cycles);
+#endif
     return hit;
 }
 

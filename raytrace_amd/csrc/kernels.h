@@ -46,6 +46,9 @@ void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int i
 void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode, double* film, hipStream_t s);
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s);
 // src and dst: packed dx*dy RGBA8 device images; tmp: dx*dy*3 float64
+#ifdef RT_VISIT_STATS
+void debug_packet_stats(unsigned long long* out8, bool reset);  // diagnostics build only
+#endif
 void launch_filter(const uint8_t* src, int32_t w, int32_t h, int filter, double* tmp, uint8_t* dst, hipStream_t s);
 void launch_intersect_batch(const DScene& sc, const double* o, const double* d, uint64_t n, double tmin, double tmax, int mode,
                             rt_hit* hits, hipStream_t s);

@@ -37,6 +37,9 @@ extern __shared__ int32_t dyn_lds[];
 #ifndef RT_PACKET_WAVES
 #define RT_PACKET_WAVES 4  // the same for the primary kernel of mesh-only scenes (wave-packet traversal)
 #endif
+#ifndef RT_PACKET_SHADE_WAVES
+#define RT_PACKET_SHADE_WAVES 4  // ... and when that kernel also runs Material.Resolve
+#endif
 #ifndef RT_FAST_WAVES
 #define RT_FAST_WAVES 3
 #endif
@@ -51,7 +54,7 @@ struct SceneHit {
     int leaf;      // >= 0: position of the face in leaf order, attributes pending; c.u / c.v hold the barycentrics
 };
 
-template <int MODE>
+template <int MODE, bool PACKET>
 RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, VisitCounts& cnt,
                               LdsStack ls);
 
@@ -59,7 +62,8 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
 // are unwound iteratively: the ray goes through each inverse transform (direction not
 // renormalised, so t is preserved), the innermost shape is intersected, and the hit point and
 // normal come back through the forward transforms.
-template <int MODE>
+// PACKET (fast mode): the lanes of the wave trace neighbouring rays and walk a mesh together (mesh_collide_packet).
+template <int MODE, bool PACKET = false>
 RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in, double tmin, double tmax, Col& c, int& prim,
                           VisitCounts& cnt, LdsStack ls) {
     Ray r = r_in;
@@ -83,7 +87,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
         case RT_SHAPE_QUAD: hit = quad_collide(sc.quads[index], r, tmin, tmax, c); break;
         case RT_SHAPE_CYLINDER: hit = cylinder_collide(sc.cylinders[index], r, tmin, tmax, c); break;
         case RT_SHAPE_TRIANGLE: hit = tri_collide(sc.tris[index], r, tmin, tmax, c); break;
-        case RT_SHAPE_MESH: hit = mesh_node_collide<MODE>(sc, index, r, tmin, tmax, c, prim, cnt, ls); break;
+        case RT_SHAPE_MESH: hit = mesh_node_collide<MODE, PACKET>(sc, index, r, tmin, tmax, c, prim, cnt, ls); break;
         default: break;
     }
     if (hit) {
@@ -97,7 +101,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
 }
 
 // Mesh.Collide for a top-level (untransformed) mesh node, attributes of the winning face included.
-template <int MODE>
+template <int MODE, bool PACKET>
 RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, VisitCounts& cnt,
                               LdsStack ls) {
     const DMesh& m = sc.meshes[index];
@@ -105,6 +109,7 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
     int p = 0;
     bool hit;
     if (MODE == RT_MODE_REFERENCE) hit = mesh_collide_ref(sc, m, r, tmin, tmax, p, t, u, v, cnt);
+    else if (PACKET) hit = mesh_collide_packet<false>(sc, m, r, tmin, tmax, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt);
     else hit = mesh_collide_fast<false>(sc, m, r, tmin, tmax, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt);
     if (hit) {
         const double* pos = sc.prim_pos + (m.prim_off + p) * 9;
@@ -144,7 +149,7 @@ RT_DEV bool node_box_reachable(const double* b, const Ray& r, V3 inv, double tmi
 
 // The node loop of tracePath (render.go:155-169).  MESH_ONLY: the host has checked that every
 // node is a plain mesh, so the other shapes' code (and its registers) is left out.
-// PACKET (fast mode, mesh-only scenes): the lanes of the wave trace neighbouring rays and walk each mesh together.
+// PACKET (fast mode): the lanes of the wave trace neighbouring rays and walk each mesh together.
 template <int MODE, bool MESH_ONLY = false, bool PACKET = false>
 RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, LdsStack ls) {
     double min_dist = tmax;
@@ -176,7 +181,7 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
         if (cull && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
         Col c;
         int prim;
-        const bool got = shape_collide<MODE>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, ls);
+        const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, ls);
         if (got && c.t < min_dist) {
             min_dist = c.t;
             h.c = c;
@@ -402,7 +407,14 @@ template <int MODE, bool MESH_ONLY, bool PACKET = false>
 RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, uint32_t& n_left, LdsStack ls) {
     if (bad3(r.o) || bad3(r.d)) return 0;  // render.go:147-150
     VisitCounts cnt{0, 0};
-    if (!scene_closest<MODE, MESH_ONLY, PACKET>(sc, r, kEps, kMaxFloat, h, cnt, ls)) {
+#ifdef RT_VISIT_STATS
+    const long long closest_t0 = clock64();
+#endif
+    const bool any = scene_closest<MODE, MESH_ONLY, PACKET>(sc, r, kEps, kMaxFloat, h, cnt, ls);
+#ifdef RT_VISIT_STATS
+    RT_STAT(12, clock64() - closest_t0);
+#endif
+    if (!any) {
         n_left++;
         return 0;
     }
@@ -417,6 +429,91 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 }
 
 // ---- kernels -----------------------------------------------------------------------------------
+
+// One work item of a primary pass: pass.block_px consecutive pixels (sub-block `sub`) of tile v, all samples of the
+// pass, traced by one wave (lane p of it).  See k_primary for how lanes are dealt to samples and pixels.
+template <int MODE, bool MESH_ONLY, bool SHADE>
+RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, double* __restrict__ film, long long v,
+                         uint32_t sub, int p, LdsStack ls, uint32_t& n_total, uint32_t& n_left) {
+    const int lanes_s = 1 << pass.log2_s;       // lanes (= samples in flight) per pixel
+    const int px_per_iter = 64 >> pass.log2_s;  // pixels a wave traces at a time
+    const int my_px = p >> pass.log2_s, my_s = p & (lanes_s - 1);
+    const int rounds = (pass.sample_count + lanes_s - 1) >> pass.log2_s;
+    const int64_t tile = pass.tile_begin + v;
+    const int64_t group = tile >> 6;
+    const int w = (int)(tile & 63);
+    const int tile_x = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8;
+    const int tile_y = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8;
+    for (int pb = 0; pb < pass.block_px; pb += px_per_iter) {
+        const int pix = (int)sub * pass.block_px + pb + my_px;  // index of this lane's pixel inside the tile, row-major
+        const int lx = tile_x + (pix & 7);
+        const int ly = tile_y + (pix >> 3);
+        const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
+        const bool live = lx < pass.dx && ly < pass.local_rows && row < pass.dy;
+        if (__ballot(live) == 0) continue;  // outside the frame
+        const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
+        const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
+        V3 acc = mk(0, 0, 0);
+        for (int round = 0; round < rounds; round++) {
+#ifdef RT_VISIT_STATS
+            const long long round_t0 = clock64();
+#endif
+            const int k = (round << pass.log2_s) + my_s;
+            const int s = pass.sample_begin + k;
+            bool want = false;
+            Ray r;
+            SceneHit h;
+            PathState ps;
+            if (live && k < pass.sample_count) {
+                // Opaque copies: without them the compiler hoists everything that depends only on the pixel (the first
+                // Philox round, the int -> double conversions) out of this loop and then has to spill it to scratch
+                // across the traversal; recomputing a dozen instructions per sample is far cheaper.
+                int lxv = lx, yv = y;
+                asm volatile("" : "+v"(lxv), "+v"(yv));
+                Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(yv * pass.dx + lxv), (uint32_t)s, 1u, 0u};
+                double fs, ft;
+                if (pass.spp == 1) {  // render.go:202-210
+                    fs = ((double)lxv + 0.5) / (double)pass.dx;
+                    ft = ((double)yv + 0.5) / (double)pass.dy;
+                } else {
+                    fs = ((double)lxv + rng.float64()) / (double)pass.dx;
+                    ft = ((double)yv + rng.float64()) / (double)pass.dy;
+                }
+                r = camera_cast(cam, fs, ft, rng);
+                n_total++;
+#ifdef RT_VISIT_STATS
+                RT_STAT(13, clock64() - round_t0);
+#endif
+                V3 em;
+                const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST>(sc, r, mk(1, 1, 1), h, em, n_left, ls);
+                if (what == 1) acc = acc + em;
+                want = what == 2;
+                ps.rad = mk(1, 1, 1);
+                ps.pixel = pixel;
+                ps.sample = (uint32_t)s;
+                ps.path = 1;
+                ps.depth_n = rng.n;
+            }
+            if (SHADE) acc = acc + shade_lane(sc, pass, q, 0, want, r, ps, h);
+#ifdef RT_VISIT_STATS
+            RT_STAT(9, clock64() - round_t0);
+            RT_STAT(10, 1);
+#endif
+        }
+        // sum over the lanes of a pixel (they are adjacent: xor-shuffles below lanes_s stay inside the pixel)
+        for (int off = lanes_s >> 1; off > 0; off >>= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64);
+        }
+        if (live && my_s == 0) {  // the only writer of this pixel during the launch
+            double* f = film + (size_t)pixel * 3;
+            if (acc.x != 0) f[0] += acc.x;
+            if (acc.y != 0) f[1] += acc.y;
+            if (acc.z != 0) f[2] += acc.z;
+        }
+    }
+}
 
 // renderPixel (render.go:186-217) for one pass.  Persistent single-wave workgroups pull work items from a
 // queue until the pass is drained.
@@ -437,7 +534,7 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // SHADE = false: the host has checked that every material only emits, so no hit ever needs Material.Resolve and
 // its code (and registers) is left out.
 template <int MODE, bool MESH_ONLY, bool SHADE>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY ? RT_PACKET_WAVES : RT_FAST_WAVES) : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY ? (SHADE ? RT_PACKET_SHADE_WAVES : RT_PACKET_WAVES) : RT_FAST_WAVES) : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
     // The camera and the queue descriptors are read through pointers where they are used: as by-value arguments
     // their ~100 dwords would sit in SGPRs for the whole kernel and push other scalars out into VGPR lanes.
     const DCamera& cam = *camp;
@@ -445,11 +542,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
     Counters* const counters = q.counters;
     const int p = (int)threadIdx.x;
     const int64_t n_tiles = pass.n_pixels >> 6;
-    const int lanes_s = 1 << pass.log2_s;                 // lanes (= samples in flight) per pixel
-    const int px_per_iter = 64 >> pass.log2_s;            // pixels a wave traces at a time
     const uint32_t n_sub = 64u / (uint32_t)pass.block_px;  // items per tile
-    const int my_px = p >> pass.log2_s, my_s = p & (lanes_s - 1);
-    const int rounds = (pass.sample_count + lanes_s - 1) >> pass.log2_s;
     const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
     uint32_t n_total = 0, n_left = 0;
     // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
@@ -486,70 +579,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         if (v < 0) break;
         const long long t_start = pass.cost ? clock64() : 0;
         sub = __shfl(sub, 0, 64);
-        const int64_t tile = pass.tile_begin + v;
-        const int64_t group = tile >> 6;
-        const int w = (int)(tile & 63);
-        const int tile_x = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8;
-        const int tile_y = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8;
-        for (int pb = 0; pb < pass.block_px; pb += px_per_iter) {
-            const int pix = (int)sub * pass.block_px + pb + my_px;  // index of this lane's pixel inside the tile, row-major
-            const int lx = tile_x + (pix & 7);
-            const int ly = tile_y + (pix >> 3);
-            const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
-            const bool live = lx < pass.dx && ly < pass.local_rows && row < pass.dy;
-            if (__ballot(live) == 0) continue;  // outside the frame
-            const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
-            const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
-            V3 acc = mk(0, 0, 0);
-            for (int round = 0; round < rounds; round++) {
-                const int k = (round << pass.log2_s) + my_s;
-                const int s = pass.sample_begin + k;
-                bool want = false;
-                Ray r;
-                SceneHit h;
-                PathState ps;
-                if (live && k < pass.sample_count) {
-                    // Opaque copies: without them the compiler hoists everything that depends only on the pixel (the first
-                    // Philox round, the int -> double conversions) out of this loop and then has to spill it to scratch
-                    // across the traversal; recomputing a dozen instructions per sample is far cheaper.
-                    int lxv = lx, yv = y;
-                    asm volatile("" : "+v"(lxv), "+v"(yv));
-                    Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(yv * pass.dx + lxv), (uint32_t)s, 1u, 0u};
-                    double fs, ft;
-                    if (pass.spp == 1) {  // render.go:202-210
-                        fs = ((double)lxv + 0.5) / (double)pass.dx;
-                        ft = ((double)yv + 0.5) / (double)pass.dy;
-                    } else {
-                        fs = ((double)lxv + rng.float64()) / (double)pass.dx;
-                        ft = ((double)yv + rng.float64()) / (double)pass.dy;
-                    }
-                    r = camera_cast(cam, fs, ft, rng);
-                    n_total++;
-                    V3 em;
-                    const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST && MESH_ONLY>(sc, r, mk(1, 1, 1), h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
-                    if (what == 1) acc = acc + em;
-                    want = what == 2;
-                    ps.rad = mk(1, 1, 1);
-                    ps.pixel = pixel;
-                    ps.sample = (uint32_t)s;
-                    ps.path = 1;
-                    ps.depth_n = rng.n;
-                }
-                if (SHADE) acc = acc + shade_lane(sc, pass, q, 0, want, r, ps, h);
-            }
-            // sum over the lanes of a pixel (they are adjacent: xor-shuffles below lanes_s stay inside the pixel)
-            for (int off = lanes_s >> 1; off > 0; off >>= 1) {
-                acc.x += __shfl_xor(acc.x, off, 64);
-                acc.y += __shfl_xor(acc.y, off, 64);
-                acc.z += __shfl_xor(acc.z, off, 64);
-            }
-            if (live && my_s == 0) {  // the only writer of this pixel during the launch
-                double* f = film + (size_t)pixel * 3;
-                if (acc.x != 0) f[0] += acc.x;
-                if (acc.y != 0) f[1] += acc.y;
-                if (acc.z != 0) f[2] += acc.z;
-            }
-        }
+        primary_item<MODE, MESH_ONLY, SHADE>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, n_total, n_left);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
     wave_tally(counters, n_total, n_left, 0);
@@ -720,7 +750,7 @@ void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, 
     if (pass.n_pixels <= 0) return;
     size_t lds = stack_bytes(sc, mode);
     // wave-packet traversal: one distance per lane and level, one reference per level
-    if (mode == RT_MODE_FAST && mesh_only) lds = (size_t)sc.stack_pairs * (kTraceBlock + kTraceBlock / 64) * sizeof(int32_t);
+    if (mode == RT_MODE_FAST) lds = (size_t)sc.stack_pairs * (kTraceBlock + kTraceBlock / 64) * sizeof(int32_t);
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);
@@ -758,6 +788,16 @@ void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode,
     else
         hipLaunchKernelGGL(k_direct<RT_MODE_FAST>, grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, film);
 }
+
+#ifdef RT_VISIT_STATS
+void debug_packet_stats(unsigned long long* out8, bool reset) {  // out8: 16 values
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_packet_stats), 16 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned long long zero[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_packet_stats), zero, sizeof(zero));
+    }
+}
+#endif
 
 // ---- reconstruction filter (reconstruct.go:28-167) ---------------------------------------------
 

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -414,6 +415,19 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         s0 += s_count;
     }
     if (int rc = read_counters()) return rc;
+#ifdef RT_VISIT_STATS
+    {
+        unsigned long long ps[16];
+        debug_packet_stats(ps, true);
+        const double w = ps[0] ? (double)ps[0] : 1.0, rounds = ps[10] ? (double)ps[10] : 1.0;
+        fprintf(stderr, "[rt] packet walks %llu: per walk %.2f inner nodes, %.2f leaves, %.2f float32 face tests, %.2f float64 face tests, %.2f pops, %.2f pushes\n",
+                ps[0], ps[1] / w, ps[2] / w, ps[3] / w, ps[4] / w, ps[5] / w, ps[6] / w);
+        fprintf(stderr, "[rt] wave rounds %llu: %.0f cycles each on average; walks %.0f cycles each (%.0f of them in leaves), %.1f %% of all round cycles\n",
+                ps[10], ps[9] / rounds, ps[8] / w, ps[11] / w, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0);
+        fprintf(stderr, "[rt] share of round cycles: ray generation %.1f %%, closest hit (set-up + walk) %.1f %%, rest (attributes, shading, film) %.1f %%\n",
+                100.0 * ps[13] / (double)ps[9], 100.0 * ps[12] / (double)ps[9], 100.0 * ((double)ps[9] - ps[13] - ps[12]) / (double)ps[9]);
+    }
+#endif
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->total_rays = host.total;
