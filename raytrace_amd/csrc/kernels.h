@@ -18,6 +18,7 @@ struct PassDesc {
     int32_t max_depth;
     int32_t log2_s;                 // primary launch: 2^log2_s lanes of a wave trace samples of the same pixel
     int32_t block_px;               // primary launch: pixels of an 8x8 tile per work item (power of two >= 64 >> log2_s)
+    int32_t acc_offset, pad0;       // primary launch: where the pixels' running sums start in dynamic LDS, in dwords (set by launch_primary)
     int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group
     int64_t n_pixels;               // tiles * 64 = pixels (threads) of this pass
     uint32_t seed_lo, seed_hi;

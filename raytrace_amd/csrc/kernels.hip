@@ -401,11 +401,11 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
 }
 
 // The first half of tracePath for one ray (render.go:143-173): NaN guard, closest hit, miss.
-// Returns 0 = nothing further (invalid ray or miss), 1 = hit an emitting-only material
+// Returns -1 = invalid ray, 0 = the ray left the scene, 1 = hit an emitting-only material
 // (`emission` set), 2 = hit needs Material.Resolve (`h` set).
 template <int MODE, bool MESH_ONLY, bool PACKET = false>
-RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, uint32_t& n_left, LdsStack ls) {
-    if (bad3(r.o) || bad3(r.d)) return 0;  // render.go:147-150
+RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, LdsStack ls) {
+    if (bad3(r.o) || bad3(r.d)) return -1;  // render.go:147-150
     VisitCounts cnt{0, 0};
 #ifdef RT_VISIT_STATS
     const long long closest_t0 = clock64();
@@ -414,10 +414,7 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 #ifdef RT_VISIT_STATS
     RT_STAT(12, clock64() - closest_t0);
 #endif
-    if (!any) {
-        n_left++;
-        return 0;
-    }
+    if (!any) return 0;
     const rt_material& m = sc.materials[sc.nodes[h.node].material];
     if (terminal_kind(m.kind)) {
         finish_hit(sc, r, h, m.kind == RT_MAT_DEBUG_NORMAL);
@@ -434,7 +431,7 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // pass, traced by one wave (lane p of it).  See k_primary for how lanes are dealt to samples and pixels.
 template <int MODE, bool MESH_ONLY, bool SHADE>
 RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, double* __restrict__ film, long long v,
-                         uint32_t sub, int p, LdsStack ls, uint32_t& n_total, uint32_t& n_left) {
+                         uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left) {
     const int lanes_s = 1 << pass.log2_s;       // lanes (= samples in flight) per pixel
     const int px_per_iter = 64 >> pass.log2_s;  // pixels a wave traces at a time
     const int my_px = p >> pass.log2_s, my_s = p & (lanes_s - 1);
@@ -453,18 +450,22 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
         if (__ballot(live) == 0) continue;  // outside the frame
         const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
         const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
-        V3 acc = mk(0, 0, 0);
+        // The pixel's running sum lives in LDS (acc_lds[c * 64], this lane's column), not in registers: it is touched once
+        // per sample and would otherwise be carried, or spilled, across every walk.
+        acc_lds[0] = 0; acc_lds[64] = 0; acc_lds[128] = 0;
         for (int round = 0; round < rounds; round++) {
 #ifdef RT_VISIT_STATS
             const long long round_t0 = clock64();
 #endif
             const int k = (round << pass.log2_s) + my_s;
             const int s = pass.sample_begin + k;
-            bool want = false;
+            bool want = false, missed = false;
             Ray r;
             SceneHit h;
             PathState ps;
-            if (live && k < pass.sample_count) {
+            const bool traced = live && k < pass.sample_count;
+            n_total += (uint32_t)__popcll(__ballot(traced));  // wave-uniform tallies: one value per wave, not per lane
+            if (traced) {
                 // Opaque copies: without them the compiler hoists everything that depends only on the pixel (the first
                 // Philox round, the int -> double conversions) out of this loop and then has to spill it to scratch
                 // across the traversal; recomputing a dozen instructions per sample is far cheaper.
@@ -480,26 +481,31 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                     ft = ((double)yv + rng.float64()) / (double)pass.dy;
                 }
                 r = camera_cast(cam, fs, ft, rng);
-                n_total++;
 #ifdef RT_VISIT_STATS
                 RT_STAT(13, clock64() - round_t0);
 #endif
                 V3 em;
-                const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST>(sc, r, mk(1, 1, 1), h, em, n_left, ls);
-                if (what == 1) acc = acc + em;
+                const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST>(sc, r, mk(1, 1, 1), h, em, ls);
+                if (what == 1) { acc_lds[0] += em.x; acc_lds[64] += em.y; acc_lds[128] += em.z; }
                 want = what == 2;
+                missed = what == 0;
                 ps.rad = mk(1, 1, 1);
                 ps.pixel = pixel;
                 ps.sample = (uint32_t)s;
                 ps.path = 1;
                 ps.depth_n = rng.n;
             }
-            if (SHADE) acc = acc + shade_lane(sc, pass, q, 0, want, r, ps, h);
+            n_left += (uint32_t)__popcll(__ballot(missed));
+            if (SHADE) {
+                const V3 em2 = shade_lane(sc, pass, q, 0, want, r, ps, h);
+                if (want) { acc_lds[0] += em2.x; acc_lds[64] += em2.y; acc_lds[128] += em2.z; }
+            }
 #ifdef RT_VISIT_STATS
             RT_STAT(9, clock64() - round_t0);
             RT_STAT(10, 1);
 #endif
         }
+        V3 acc = mk(acc_lds[0], acc_lds[64], acc_lds[128]);
         // sum over the lanes of a pixel (they are adjacent: xor-shuffles below lanes_s stay inside the pixel)
         for (int off = lanes_s >> 1; off > 0; off >>= 1) {
             acc.x += __shfl_xor(acc.x, off, 64);
@@ -579,10 +585,14 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         if (v < 0) break;
         const long long t_start = pass.cost ? clock64() : 0;
         sub = __shfl(sub, 0, 64);
-        primary_item<MODE, MESH_ONLY, SHADE>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, n_total, n_left);
+        primary_item<MODE, MESH_ONLY, SHADE>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
+                                             reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
-    wave_tally(counters, n_total, n_left, 0);
+    if (p == 0) {  // the tallies are per wave already
+        if (n_total) atomicAdd(&counters->total, (unsigned long long)n_total);
+        if (n_left) atomicAdd(&counters->left, (unsigned long long)n_left);
+    }
 }
 
 template <int MODE, bool MESH_ONLY>
@@ -604,7 +614,8 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
         ps.path = rays.path[i];
         ps.depth_n = rays.depth_n[i];
         V3 em;
-        const int what = trace_one<MODE, MESH_ONLY>(sc, r, ps.rad, h, em, n_left, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
+        const int what = trace_one<MODE, MESH_ONLY>(sc, r, ps.rad, h, em, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
+        if (what == 0) n_left = 1;
         if (what == 1) film_add(film, ps.pixel, em);
         want = what == 2;
     }
@@ -751,11 +762,16 @@ void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, 
     size_t lds = stack_bytes(sc, mode);
     // wave-packet traversal: one distance per lane and level, one reference per level
     if (mode == RT_MODE_FAST) lds = (size_t)sc.stack_pairs * (kTraceBlock + kTraceBlock / 64) * sizeof(int32_t);
+    // behind the stack: the running sums of the pixels being traced, three float64 per lane
+    lds = (lds + 7) & ~(size_t)7;
+    PassDesc pd = pass;
+    pd.acc_offset = (int32_t)(lds / sizeof(int32_t));
+    lds += (size_t)3 * kTraceBlock * sizeof(double);
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);
         const dim3 grid(std::min(resident, (tiles + 7u) & ~7u)), block(kTraceBlock);
-        hipLaunchKernelGGL(kernel, grid, block, lds, s, sc, cam, pass, q, film);
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, sc, cam, pd, q, film);
     };
     auto pick = [&](auto mode_tag) {
         constexpr int M = decltype(mode_tag)::value;
