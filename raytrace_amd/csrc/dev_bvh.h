@@ -356,20 +356,44 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
     int sp = 0;       // wave-uniform
     float cur_tn = tmin32;
     bool hit = false;
-    for (;;) {
-        if (cur >= 0) {  // inner node: test both children; go to the one most lanes reach first, push the other
+    // direction signs over the lanes whose rays reach the mesh (a zero component counts by the sign slab_inverse gave it)
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(alive);
+    const unsigned long long ngx = __builtin_amdgcn_ballot_w64(alive && f.ix < 0.0f), ngy = __builtin_amdgcn_ballot_w64(alive && f.iy < 0.0f),
+                             ngz = __builtin_amdgcn_ballot_w64(alive && f.iz < 0.0f);
+    const bool same = (ngx == 0 || ngx == act) && (ngy == 0 || ngy == act) && (ngz == 0 || ngz == act);
+    const int oct = same ? ((ngx != 0 ? 1 : 0) | (ngy != 0 ? 2 : 0) | (ngz != 0 ? 4 : 0)) : -1;
+    // Inner nodes, from `cur` down to the next leaf (left in `cur`; kDone when the walk is over): test both children, go
+    // to the one most lanes reach first, push the other; with nothing reached, pop.
+    // O >= 0: every ray of the wave runs into octant O (bit a set = down axis a), so which plane of a slab is entered and
+    // which is left is known when the code is compiled: the packed multiply-add gets the two planes in that order (an
+    // operand-select bit, no instruction) and the per-lane minimum / maximum of each pair of distances falls away,
+    // 12 of a node's 36 vector instructions.  O < 0: rays of mixed octants, planes sorted per lane.
+    // Only this loop exists once per octant; the leaves' float64 code below is shared.
+    auto descend = [&](auto oct_tag) {
+        constexpr int O = decltype(oct_tag)::value;
+        while (cur >= 0) {
             const FastNode n = load_node_scalar(nodes, cur);
             RT_STAT(1, 1);
             cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
             float tn[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][0], n.b[k][0][1]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
-                const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][0], n.b[k][1][1]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
-                const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][0], n.b[k][2][1]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
-                const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), tmin32));
-                const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), tmax32));
-                tn[k] = (tnear <= tfar) ? tnear : inf32;
+                if (O >= 0) {
+                    constexpr int sx = O >= 0 ? (O & 1) : 0, sy = O >= 0 ? ((O >> 1) & 1) : 0, sz = O >= 0 ? ((O >> 2) & 1) : 0;
+                    const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][sx], n.b[k][0][1 - sx]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
+                    const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][sy], n.b[k][1][1 - sy]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
+                    const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][sz], n.b[k][2][1 - sz]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
+                    const float tnear = fmaxf(fmaxf(x[0], y[0]), fmaxf(z[0], tmin32));
+                    const float tfar = fminf(fminf(x[1], y[1]), fminf(z[1], tmax32));
+                    tn[k] = (tnear <= tfar) ? tnear : inf32;
+                } else {
+                    const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][0], n.b[k][0][1]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
+                    const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][0], n.b[k][1][1]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
+                    const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][0], n.b[k][2][1]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
+                    const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), tmin32));
+                    const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), tmax32));
+                    tn[k] = (tnear <= tfar) ? tnear : inf32;
+                }
             }
             const bool go0 = tn[0] < inf32, go1 = tn[1] < inf32;
             const unsigned long long m0 = n.child[0] != kFastEmpty ? __builtin_amdgcn_ballot_w64(go0) : 0ull;
@@ -385,14 +409,39 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
                 }
                 cur = swap ? n.child[1] : n.child[0];
                 cur_tn = swap ? tn[1] : tn[0];
-                continue;
-            }
-            if ((m0 | m1) != 0) {
+            } else if ((m0 | m1) != 0) {
                 cur = m1 != 0 ? n.child[1] : n.child[0];
                 cur_tn = m1 != 0 ? tn[1] : tn[0];
-                continue;
+            } else {
+                cur = kDone;
+                while (sp > 0) {  // pop, skipping subtrees that begin beyond every lane's current hit
+                    sp--;
+                    RT_STAT(5, 1);
+                    const float tnear = __int_as_float(lds[sp * stride]);
+                    if (__builtin_amdgcn_ballot_w64(tnear <= tmax32) != 0) {
+                        cur = __builtin_amdgcn_readfirstlane(refs[sp]);
+                        cur_tn = tnear;
+                        break;
+                    }
+                }
+                if (cur == kDone) return;
             }
-        } else {  // leaf
+        }
+    };
+    for (;;) {
+        switch (oct) {
+            case 0: descend(std::integral_constant<int, 0>{}); break;
+            case 1: descend(std::integral_constant<int, 1>{}); break;
+            case 2: descend(std::integral_constant<int, 2>{}); break;
+            case 3: descend(std::integral_constant<int, 3>{}); break;
+            case 4: descend(std::integral_constant<int, 4>{}); break;
+            case 5: descend(std::integral_constant<int, 5>{}); break;
+            case 6: descend(std::integral_constant<int, 6>{}); break;
+            case 7: descend(std::integral_constant<int, 7>{}); break;
+            default: descend(std::integral_constant<int, -1>{}); break;
+        }
+        if (cur == kDone) break;
+        {  // leaf
             const uint32_t code = (uint32_t)~cur;
             const int32_t first = (int32_t)(code >> 3);
             const int32_t count = (int32_t)(code & 7u) + 1;
