@@ -203,6 +203,12 @@ struct Flattener {
             f.b[k][a][1] = round_up(b.mx[a] - out.center[a]) + out.pad;
         }
     }
+    // An empty slot gets an inverted box (min above max on every axis): a slab test that takes the planes in the order
+    // the ray meets them finds its entry beyond its exit for every ray, so such a test needs no look at the reference.
+    static void set_empty(FastNode& f, int k) {
+        for (int a = 0; a < 3; a++) { f.b[k][a][0] = 1.0f; f.b[k][a][1] = -1.0f; }
+        f.child[k] = kFastEmpty;
+    }
     Box range_box(uint32_t first, uint32_t count) const {
         Box b = face_box[order[first]];
         for (uint32_t i = 1; i < count; i++) b = unite(b, face_box[order[first + i]]);
@@ -231,6 +237,7 @@ struct Flattener {
             FastNode f = out.fast_nodes[me];
             set_box(f, k, b);
             f.child[k] = ref;
+            if (ref == kFastEmpty) set_empty(f, k);
             out.fast_nodes[me] = f;
         }
         return me;
@@ -252,6 +259,7 @@ struct Flattener {
             FastNode f = out.fast_nodes[me];
             set_box(f, k, kids[k]->box);
             f.child[k] = ref;
+            if (ref == kFastEmpty) set_empty(f, k);
             out.fast_nodes[me] = f;
         }
         return me;
@@ -302,8 +310,8 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
         FastNode f = out.fast_nodes[0];
         fl.set_box(f, 0, root->box);
         f.child[0] = ref;
-        f.child[1] = kFastEmpty;
-        for (int a = 0; a < 3; a++) { f.b[1][a][0] = 1.0f; f.b[1][a][1] = -1.0f; }
+        if (ref == kFastEmpty) Flattener::set_empty(f, 0);
+        Flattener::set_empty(f, 1);
         out.fast_nodes[0] = f;
     }
 

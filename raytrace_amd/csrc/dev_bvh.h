@@ -310,6 +310,12 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
     return hit;
 }
 
+// Two-input maximum / minimum as single instructions, without the canonicalisation of the operands that the compiler
+// puts in front of fmaxf / fminf when it cannot prove them canonical (every operand here is a finite number or an
+// infinity by construction).
+RT_DEV float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // Diagnostics of the packet walk (builds with -DRT_VISIT_STATS only): events per wave, summed over the launch.
 #ifdef RT_VISIT_STATS
 __device__ unsigned long long g_packet_stats[16];  // walks, inner nodes, leaves, float32 face tests, float64 face tests, pops, pushes, -, cycles in walks, cycles in rounds, rounds, cycles in leaves
@@ -376,28 +382,31 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
             RT_STAT(1, 1);
             cnt.boxes += 2;  // diagnostics only; dead code unless the caller reads the counts
             float tn[2];
+            unsigned long long reach[2];  // lanes whose rays enter the child's box
 #pragma unroll
             for (int k = 0; k < 2; k++) {
+                bool in_k;
+                float tnear;
                 if (O >= 0) {
                     constexpr int sx = O >= 0 ? (O & 1) : 0, sy = O >= 0 ? ((O >> 1) & 1) : 0, sz = O >= 0 ? ((O >> 2) & 1) : 0;
                     const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][sx], n.b[k][0][1 - sx]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
                     const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][sy], n.b[k][1][1 - sy]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
                     const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][sz], n.b[k][2][1 - sz]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
-                    const float tnear = fmaxf(fmaxf(x[0], y[0]), fmaxf(z[0], tmin32));
-                    const float tfar = fminf(fminf(x[1], y[1]), fminf(z[1], tmax32));
-                    tn[k] = (tnear <= tfar) ? tnear : inf32;
+                    tnear = fmaxf(fmaxf(x[0], y[0]), max_raw(z[0], tmin32));
+                    const float tfar = fminf(fminf(x[1], y[1]), min_raw(z[1], tmax32));
+                    in_k = tnear <= tfar;  // an empty slot holds an inverted box, which this ordered test can never enter
                 } else {
                     const f32x2 x = __builtin_elementwise_fma(f32x2{n.b[k][0][0], n.b[k][0][1]}, f32x2{f.ix, f.ix}, f32x2{f.nx, f.nx});
                     const f32x2 y = __builtin_elementwise_fma(f32x2{n.b[k][1][0], n.b[k][1][1]}, f32x2{f.iy, f.iy}, f32x2{f.ny, f.ny});
                     const f32x2 z = __builtin_elementwise_fma(f32x2{n.b[k][2][0], n.b[k][2][1]}, f32x2{f.iz, f.iz}, f32x2{f.nz, f.nz});
-                    const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), tmin32));
-                    const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), tmax32));
-                    tn[k] = (tnear <= tfar) ? tnear : inf32;
+                    tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), max_raw(fminf(z[0], z[1]), tmin32));
+                    const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), min_raw(fmaxf(z[0], z[1]), tmax32));
+                    in_k = (tnear <= tfar) & (n.child[k] != kFastEmpty);  // the sorting test would enter an inverted box
                 }
+                reach[k] = __builtin_amdgcn_ballot_w64(in_k);
+                tn[k] = in_k ? tnear : inf32;
             }
-            const bool go0 = tn[0] < inf32, go1 = tn[1] < inf32;
-            const unsigned long long m0 = n.child[0] != kFastEmpty ? __builtin_amdgcn_ballot_w64(go0) : 0ull;
-            const unsigned long long m1 = n.child[1] != kFastEmpty ? __builtin_amdgcn_ballot_w64(go1) : 0ull;
+            const unsigned long long m0 = reach[0], m1 = reach[1];
             if (m0 != 0 && m1 != 0) {
                 const unsigned long long first1 = __builtin_amdgcn_ballot_w64(tn[1] < tn[0]);  // lanes that reach child 1 first
                 const bool swap = 2 * __popcll(first1) > __popcll(m0 | m1);
