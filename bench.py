@@ -142,17 +142,18 @@ def main():
     fence()
     t_begin = time.perf_counter()
     rays = trav_s = 0.0
-    trav_launches = trav_rays = 0
+    trav_launches = trav_rays = culled = 0
     for k in range(a.steps):
         st = step(k)
         rays += st.total_rays
         trav_s += st.traverse_seconds
         trav_launches += st.traverse_launches
         trav_rays += st.traverse_rays
+        culled += st.culled_rays
     shard.combine_films(film)  # the per-GPU films hold disjoint row bands: one sum onto rank 0 assembles the frame
     fence()
     elapsed = time.perf_counter() - t_begin
-    tot = torch.tensor([rays, elapsed, trav_s, float(trav_launches), float(trav_rays)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([rays, elapsed, trav_s, float(trav_launches), float(trav_rays), float(culled)], dtype=torch.float64, device="cuda")
     tot, mx = shard.combine_counters(tot)
     elapsed = float(mx[1])  # the slowest rank's wall time
     rays_all = float(tot[0])
@@ -189,6 +190,9 @@ def main():
             "scene_upload_s": upload_s,
             "rays_per_step_all_gpus": rays_all / max(a.steps, 1),
             "rank0_kernel_ms_per_step": 1e3 * float(trav_s) / max(a.steps, 1),
+            # camera rays of 8x8 tiles that lie outside the screen bounds of the scene: counted like the reference counts
+            # them (TotalRays, RaysLeftScene), settled without being generated (RT_NO_PIXEL_CULL=1 traces them)
+            "culled_ray_fraction": float(tot[5]) / max(rays_all, 1.0),
         },
     }
     base = None

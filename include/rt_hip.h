@@ -270,6 +270,8 @@ typedef struct rt_stats { /* phys.RenderStats, render.go:38-45 */
     double traverse_seconds;      /* sum of HIP-event time of the closest-hit traversal launches */
     uint64_t traverse_launches;
     uint64_t traverse_rays;       /* rays those launches processed */
+    uint64_t culled_rays;         /* camera rays (counted in total_rays and rays_left_scene) that were not generated because their
+                                     pixel lies outside the screen bounds of every node: they cannot hit anything */
 } rt_stats;
 
 typedef struct rt_hit {

@@ -134,7 +134,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("total_rays", C.c_uint64), ("rays_exceeded_depth", C.c_uint64), ("rays_left_scene", C.c_uint64),
         ("shadow_rays", C.c_uint64), ("render_seconds", C.c_double), ("traverse_seconds", C.c_double),
-        ("traverse_launches", C.c_uint64), ("traverse_rays", C.c_uint64),
+        ("traverse_launches", C.c_uint64), ("traverse_rays", C.c_uint64), ("culled_rays", C.c_uint64),
     ]
 
 

@@ -60,6 +60,7 @@ struct rt_scene {
     rt::DeviceBuffers mem;
     rt::DScene dev{};
     std::vector<rt_bvh_info> bvh_info;
+    std::vector<double> node_box;  // host copy of DScene::node_box (6 per node): screen bounds of the scene for a camera
     std::atomic<bool> cancel{false};
     rt::WorkBuffers* work = nullptr;
     bool all_terminal = false;  // every material only emits: no shade / light-loop launches are ever needed

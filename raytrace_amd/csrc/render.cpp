@@ -42,6 +42,7 @@ struct WorkBuffers {
     std::string order_key;
     bool order_valid = false;
     uint32_t queue_off[8] = {}, queue_len[8] = {};
+    uint64_t culled_pixels = 0;  // pixels of the tiles the schedule leaves out (outside the screen bounds of the scene)
 };
 
 void destroy_work(WorkBuffers* w) {
@@ -125,6 +126,61 @@ int ensure_work(rt_scene* sc) {
     return RT_OK;
 }
 
+// Bounds of everything in the scene in the camera's image coordinates (s, t), the arguments of Camera.Cast: every ray
+// that can hit a node has s in [out[0], out[1]] and t in [out[2], out[3]].  Orthographic (camera_orthographic.go:24-46):
+// the ray through (s, t) starts at from + u * fov_w * (s - 0.5) + v * fov_h * (t - 0.5) and runs along -w, so a world
+// point lies on exactly the ray whose (s, t) are its u / v coordinates.  Pinhole (camera_pinhole.go:20-34): the ray
+// from `origin` through llc + s * horizontal + t * vertical; a point in front of the camera is solved for (s, t).
+// Returns false when there are no such bounds (cameras with a lens or distortion, a node without finite bounds, a
+// box corner beside or behind a pinhole camera).
+bool screen_bounds(const rt_scene* sc, const DCamera& cam, double out[4]) {
+    if (cam.kind != RT_CAM_ORTHOGRAPHIC && cam.kind != RT_CAM_PINHOLE) return false;
+    double lo_s = 1e300, hi_s = -1e300, lo_t = 1e300, hi_t = -1e300;
+    double inv[3][3] = {};
+    if (cam.kind == RT_CAM_PINHOLE) {  // columns of M: llc - origin, horizontal, vertical; P - origin = M * (l, l*s, l*t)
+        double m[3][3];
+        for (int r = 0; r < 3; r++) { m[r][0] = cam.llc[r] - cam.origin[r]; m[r][1] = cam.horizontal[r]; m[r][2] = cam.vertical[r]; }
+        const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        if (!(std::fabs(det) > 0) || !std::isfinite(det)) return false;
+        inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det; inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+        inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det; inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+        inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det; inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+    } else if (!(cam.fov_w > 0) || !(cam.fov_h > 0)) {
+        return false;
+    }
+    const size_t n_nodes = sc->node_box.size() / 6;
+    for (size_t i = 0; i < n_nodes; i++) {
+        const double* b = &sc->node_box[i * 6];
+        for (int k = 0; k < 6; k++)
+            if (!std::isfinite(b[k])) return false;
+        for (int c = 0; c < 8; c++) {
+            const double p[3] = {b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]};
+            double s, t;
+            if (cam.kind == RT_CAM_ORTHOGRAPHIC) {
+                double du = 0, dv = 0;
+                for (int k = 0; k < 3; k++) { du += (p[k] - cam.from[k]) * cam.u[k]; dv += (p[k] - cam.from[k]) * cam.v[k]; }
+                s = 0.5 + du / cam.fov_w;
+                t = 0.5 + dv / cam.fov_h;
+            } else {
+                double x[3] = {0, 0, 0};
+                for (int r = 0; r < 3; r++)
+                    for (int k = 0; k < 3; k++) x[r] += inv[r][k] * (p[k] - cam.origin[k]);
+                if (!(x[0] > 1e-9)) return false;  // beside or behind the camera: its image is unbounded
+                s = x[1] / x[0];
+                t = x[2] / x[0];
+            }
+            if (!std::isfinite(s) || !std::isfinite(t)) return false;
+            lo_s = std::min(lo_s, s); hi_s = std::max(hi_s, s);
+            lo_t = std::min(lo_t, t); hi_t = std::max(hi_t, t);
+        }
+    }
+    // generous against the rounding above and in Camera.Cast: a millionth of the frame plus a millionth of the extent
+    const double ms = 1e-6 * (1.0 + std::fabs(lo_s) + std::fabs(hi_s)), mt = 1e-6 * (1.0 + std::fabs(lo_t) + std::fabs(hi_t));
+    out[0] = lo_s - ms; out[1] = hi_s + ms; out[2] = lo_t - mt; out[3] = hi_t + mt;  // no nodes: an empty interval, nothing is visible
+    return true;
+}
+
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
 };
@@ -160,10 +216,32 @@ struct EventPool {  // HIP-event timing of the traversal launches, on the stream
 };
 
 // Turns the pilot pass's per-tile costs into the work order of the 8 queues.
-int build_tile_order(WorkBuffers& w, int64_t tiles_total, hipStream_t stream) {
+// Where the tiles of a pass lie in the image, and the pixel columns / rows (rows counted upward, as the reference's y,
+// render.go:195) outside which nothing of the scene can be seen (the full int32 range: no such bounds).
+struct TileGeometry {
+    int32_t dx, dy, groups_x, local_rows, band_rank, band_world;
+    int32_t cull_x[2], cull_y[2];
+    // Live pixels of tile t (k_primary's numbering) and whether all of them lie outside the bounds.
+    bool outside(int64_t t, uint32_t& live_pixels) const {
+        const int64_t group = t >> 6;
+        const int w = (int)(t & 63);
+        const int tile_x = ((int)(group % groups_x) * 8 + (w & 7)) * 8;
+        const int tile_y = ((int)(group / groups_x) * 8 + (w >> 3)) * 8;
+        const int row0 = ((tile_y >> 4) * band_world + band_rank) * 16 + (tile_y & 15);  // a tile lies inside one band of 16 rows
+        const int cols = std::max(0, std::min(8, dx - tile_x));
+        const int rows = std::max(0, std::min(8, std::min(local_rows - tile_y, dy - row0)));
+        live_pixels = (uint32_t)(cols * rows);
+        if (live_pixels == 0) return false;  // outside the frame: the kernel skips it anyway
+        const int y_hi = dy - 1 - row0, y_lo = y_hi - (rows - 1);
+        return tile_x + cols - 1 < cull_x[0] || tile_x > cull_x[1] || y_hi < cull_y[0] || y_lo > cull_y[1];
+    }
+};
+
+int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& geo, hipStream_t stream) {
     std::vector<uint32_t> cost((size_t)tiles_total);
     HIP_TRY(hipMemcpyAsync(cost.data(), w.tile_cost, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    w.culled_pixels = 0;
     std::vector<int32_t> order;
     order.reserve((size_t)tiles_total);
     double sum = 0;
@@ -180,7 +258,12 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, hipStream_t stream) {
     for (int k = 0; k < 8; k++) {
         const size_t begin = order.size();
         for (int64_t g = k; g * 64 < tiles_total; g += 8)
-            for (int t = 0; t < 64 && g * 64 + t < tiles_total; t++) order.push_back((int32_t)(g * 64 + t));
+            for (int t = 0; t < 64 && g * 64 + t < tiles_total; t++) {
+                // A tile no ray of which can hit anything is left out; the host adds its rays to the statistics.
+                uint32_t live = 0;
+                if (geo.outside(g * 64 + t, live)) { w.culled_pixels += live; continue; }
+                order.push_back((int32_t)(g * 64 + t));
+            }
         std::stable_sort(order.begin() + begin, order.end(), [&](int32_t a, int32_t b) { return klass(a) > klass(b); });
         w.queue_off[k] = (uint32_t)begin;
         w.queue_len[k] = (uint32_t)(order.size() - begin);
@@ -261,6 +344,19 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     pass.seed_lo = (uint32_t)((uint64_t)o->seed & 0xffffffffu);
     pass.seed_hi = (uint32_t)((uint64_t)o->seed >> 32);
     pass.max_depth = o->max_ray_depth;
+    TileGeometry geo{};  // filled below, once groups_x / local_rows are known
+    {   // screen bounds in whole pixels, one more on every side than the (s, t) bounds give
+        double sb[4];
+        geo.cull_x[0] = geo.cull_y[0] = INT32_MIN;
+        geo.cull_x[1] = geo.cull_y[1] = INT32_MAX;
+        if (std::getenv("RT_NO_PIXEL_CULL") == nullptr && screen_bounds(sc, cam, sb)) {
+            auto clamp_px = [](double v) { return (int32_t)std::max(-1.0e9, std::min(1.0e9, v)); };
+            geo.cull_x[0] = clamp_px(std::floor(sb[0] * o->dx) - 1);
+            geo.cull_x[1] = clamp_px(std::ceil(sb[1] * o->dx) + 1);
+            geo.cull_y[0] = clamp_px(std::floor(sb[2] * o->dy) - 1);
+            geo.cull_y[1] = clamp_px(std::ceil(sb[3] * o->dy) + 1);
+        }
+    }
     const int64_t tiles_total = (int64_t)pass.groups_x * ((local_rows + 63) / 64) * 64;  // whole groups; tiles outside the image idle
     const int s_first = o->sample_count > 0 ? o->sample_begin : 0;
     const int s_end = o->sample_count > 0 ? o->sample_begin + o->sample_count : o->rays_per_pixel;
@@ -269,7 +365,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
 
     HIP_TRY(hipMemsetAsync(q.counters, 0, sizeof(Counters), stream));
     EventPool events;
-    uint64_t traverse_launches = 0;
+    uint64_t traverse_launches = 0, culled_rays = 0;
     Counters host{};
     uint64_t pool_top = 0;
 
@@ -286,7 +382,9 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
 
     // Cost-ordered schedule: worth a pilot pass when the frame has many tiles and more than a few samples.
     const std::string order_key = std::string(reinterpret_cast<const char*>(camera), sizeof(*camera)) + "|" + std::to_string(o->dx) + "x" +
-                                  std::to_string(o->dy) + "|" + std::to_string(rank) + "/" + std::to_string(world) + "|" + std::to_string(o->mode);
+                                  std::to_string(o->dy) + "|" + std::to_string(rank) + "/" + std::to_string(world) + "|" + std::to_string(o->mode) + "|" +
+                                  std::to_string(geo.cull_x[0]) + ":" + std::to_string(geo.cull_x[1]) + ":" + std::to_string(geo.cull_y[0]) + ":" +
+                                  std::to_string(geo.cull_y[1]);
     const bool want_order = tiles_total >= 2048 && std::getenv("RT_NO_TILE_ORDER") == nullptr;
     if (want_order && (w.order_tiles != (size_t)tiles_total || !w.tile_cost)) {
         if (w.tile_cost) (void)hipFree(w.tile_cost);
@@ -352,6 +450,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             HIP_TRY(events.next(&ev));
             HIP_TRY(hipEventRecord(ev->a, stream));
             launch_primary(sc->dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream);
+            if (pass.order) culled_rays += w.culled_pixels * (uint64_t)s_count;  // tiles the schedule leaves out: nothing to trace
             HIP_TRY(hipEventRecord(ev->b, stream));
             HIP_TRY(hipGetLastError());
             traverse_launches++;
@@ -408,7 +507,9 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             }
         }
         if (pilot) {
-            if (int rc = build_tile_order(w, tiles_total, stream)) return rc;
+            geo.dx = o->dx; geo.dy = o->dy; geo.groups_x = pass.groups_x; geo.local_rows = pass.local_rows;
+            geo.band_rank = pass.band_rank; geo.band_world = pass.band_world;
+            if (int rc = build_tile_order(w, tiles_total, geo, stream)) return rc;
             w.order_key = order_key;
             w.order_valid = true;
         }
@@ -430,14 +531,15 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
 #endif
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        stats->total_rays = host.total;
+        stats->total_rays = host.total + culled_rays;  // rays of culled tiles count as traced and as having left the scene
         stats->rays_exceeded_depth = host.exceeded;
-        stats->rays_left_scene = host.left;
+        stats->rays_left_scene = host.left + culled_rays;
         stats->shadow_rays = host.shadow;
         stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         stats->traverse_seconds = events.ms * 1e-3;
         stats->traverse_launches = traverse_launches;
-        stats->traverse_rays = host.total;  // every counted ray went through exactly one of the timed launches
+        stats->traverse_rays = host.total + culled_rays;  // every counted ray was settled by exactly one of the timed launches
+        stats->culled_rays = culled_rays;
     }
     return RT_OK;
 }

@@ -589,6 +589,7 @@ class RenderStats:  # render.go:38-45
     TraverseSeconds: float = 0.0
     TraverseLaunches: int = 0
     TraverseRays: int = 0
+    CulledRays: int = 0  # camera rays counted (TotalRays, RaysLeftScene) without being generated: their tiles cannot see the scene
 
 
 @dataclass
@@ -859,7 +860,7 @@ class DeviceScene:
 
 def stats_from(st: abi.Stats, options: RenderOptions) -> RenderStats:
     return RenderStats(st.rays_exceeded_depth, st.rays_left_scene, st.total_rays, st.render_seconds, options.Dx,
-                       options.Dy, st.shadow_rays, st.traverse_seconds, st.traverse_launches, st.traverse_rays)
+                       options.Dy, st.shadow_rays, st.traverse_seconds, st.traverse_launches, st.traverse_rays, st.culled_rays)
 
 
 def Render(scene: Scene, mode=abi.MODE_FAST) -> RenderArtifact:

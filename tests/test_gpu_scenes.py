@@ -302,3 +302,56 @@ def test_full_size_teapot_frame_properties():
         assert rays == st.total_rays
         assert torch.allclose(acc, whole, rtol=1e-9, atol=1e-9)
         assert whole.mean().item() > 1.0  # radiance sums over 256 samples: the frame is lit
+
+
+@pytest.mark.parametrize("camera", ["orthographic", "pinhole", "pinhole_inside"])
+def test_tiles_outside_the_screen_bounds_are_settled_without_tracing(camera, monkeypatch):
+    """8x8 tiles that lie outside the image of every node's bounds are left out of the schedule (orthographic and
+    pinhole cameras, frames of >= 2048 tiles with >= 32 samples) and their rays added to the statistics by the host:
+    film sums and statistics must be those of a render that traces every tile, for one rank and for bands."""
+    import torch
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    sc = scenes.scan(level=5, dx=640, dy=1024, spp=48, tex_size=64)  # a third of the rows is still >= 2048 tiles
+    o = sc.RenderOptions
+    if camera == "orthographic":  # the scene's own camera, with a field of view the mesh does not fill
+        c0 = sc.Camera[0]
+        cam = phys.OrthographicCamera(LookFrom=c0.LookFrom, LookAt=c0.LookAt, VUp=c0.VUp, FOVHeight=800.0, FOVWidth=500.0)
+    else:
+        # looking at the mesh (around the origin) from (3, 0.5, 2) times its size; "inside": from within its bounds,
+        # where a box corner lies behind the camera and there are no screen bounds to use
+        scale = 1.0 if camera == "pinhole" else 0.05
+        r = 130.0  # the stand-in mesh reaches out to about 125 units from the origin
+        origin = np.array([3.0, 0.5, 2.0]) * r * scale
+        w = origin / np.linalg.norm(origin)
+        u = np.cross([0.0, 0.0, 1.0], w); u /= np.linalg.norm(u)
+        v = np.cross(w, u)
+        width, height, focal = 1.5, 2.4, 1.5
+        cam = phys.PinholeCamera(LowerLeftCorner=tuple(origin - u * width / 2 - v * height / 2 - w * focal), Origin=tuple(origin),
+                                 Horizontal=tuple(u * width), Vertical=tuple(v * height))
+    cd = phys.camera_desc(cam)
+
+    def film_of(dev, rank=0, world=1):
+        film = torch.zeros((o.Dy, o.Dx, 3), dtype=torch.float64, device="cuda")
+        ro = phys.render_opts(o, abi.MODE_FAST, rank, world, None, 0, 0)
+        st = abi.Stats()
+        _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
+        torch.cuda.synchronize()
+        return film, st
+
+    with phys.DeviceScene(sc) as dev:
+        for rank, world in ((0, 1), (1, 3)):
+            monkeypatch.delenv("RT_NO_PIXEL_CULL", raising=False)
+            a, sa = film_of(dev, rank, world)
+            monkeypatch.setenv("RT_NO_PIXEL_CULL", "1")
+            b, sb = film_of(dev, rank, world)
+            assert sb.culled_rays == 0
+            if camera == "pinhole_inside":
+                assert sa.culled_rays == 0
+            else:
+                assert 0 < sa.culled_rays < sa.total_rays
+            assert (sa.total_rays, sa.rays_left_scene, sa.rays_exceeded_depth) == (sb.total_rays, sb.rays_left_scene, sb.rays_exceeded_depth)
+            # (the two renders may split the samples into passes differently: float64 sums in another order)
+            assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+            assert torch.equal(a == 0, b == 0)
+            assert a.any()
