@@ -37,6 +37,7 @@ def parse():
     p.add_argument("--spp", type=int, default=1024, help="RaysPerPixel of the configuration")
     p.add_argument("--tex", type=int, default=4096)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-all-tiles-leg", action="store_true", help="skip the extra, unmeasured steps with the screen-bounds culling off")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     p.add_argument("--emulate-world", type=int, default=0,
                    help="single process renders only the row bands that rank 0 of this many ranks would own (scaling rehearsal)")
@@ -239,6 +240,21 @@ def main():
         err = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
         result["check"] = {"pixels": int(mask.sum()), "samples_per_pixel": int(spp_done), "max_rel_diff_of_sums": float(err.max()),
                            "frac_rel_diff_gt_1e-9": float((err > 1e-9).mean()), "nonzero_fraction": float((want > 0).any(axis=1).mean())}
+    if world == 1 and result["config"]["culled_ray_fraction"] > 0 and not a.emulate_world and not a.no_all_tiles_leg:
+        # The same steps once more with every tile traced (no screen-bounds culling), outside the measured region:
+        # how much of `value` the culling accounts for.  The film is scratch by now.
+        os.environ["RT_NO_PIXEL_CULL"] = "1"
+        try:
+            step(0)  # new schedule (pilot pass)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rays2 = 0
+            for k in range(a.steps):
+                rays2 += step(k).total_rays
+            torch.cuda.synchronize()
+            result["config"]["value_all_tiles_traced"] = rays2 / (time.perf_counter() - t0) / 1e6
+        finally:
+            del os.environ["RT_NO_PIXEL_CULL"]
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
