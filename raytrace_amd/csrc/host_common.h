@@ -60,7 +60,11 @@ struct rt_scene {
     rt::DeviceBuffers mem;
     rt::DScene dev{};
     std::vector<rt_bvh_info> bvh_info;
-    std::vector<double> node_box;  // host copy of DScene::node_box (6 per node): screen bounds of the scene for a camera
+    // host copies of what the screen-space occupancy map of a camera is made from
+    std::vector<double> node_box;        // DScene::node_box, 6 per node
+    std::vector<rt::DNode> nodes;
+    std::vector<rt::DMesh> meshes;
+    std::vector<rt::FastNode> fast_nodes;
     std::atomic<bool> cancel{false};
     rt::WorkBuffers* work = nullptr;
     bool all_terminal = false;  // every material only emits: no shade / light-loop launches are ever needed

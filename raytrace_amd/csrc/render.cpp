@@ -126,47 +126,45 @@ int ensure_work(rt_scene* sc) {
     return RT_OK;
 }
 
-// Bounds of everything in the scene in the camera's image coordinates (s, t), the arguments of Camera.Cast: every ray
-// that can hit a node has s in [out[0], out[1]] and t in [out[2], out[3]].  Orthographic (camera_orthographic.go:24-46):
-// the ray through (s, t) starts at from + u * fov_w * (s - 0.5) + v * fov_h * (t - 0.5) and runs along -w, so a world
-// point lies on exactly the ray whose (s, t) are its u / v coordinates.  Pinhole (camera_pinhole.go:20-34): the ray
-// from `origin` through llc + s * horizontal + t * vertical; a point in front of the camera is solved for (s, t).
-// Returns false when there are no such bounds (cameras with a lens or distortion, a node without finite bounds, a
-// box corner beside or behind a pinhole camera).
-bool screen_bounds(const rt_scene* sc, const DCamera& cam, double out[4]) {
-    if (cam.kind != RT_CAM_ORTHOGRAPHIC && cam.kind != RT_CAM_PINHOLE) return false;
-    double lo_s = 1e300, hi_s = -1e300, lo_t = 1e300, hi_t = -1e300;
+// Image of world-space boxes in the camera's image coordinates (s, t), the arguments of Camera.Cast: a ray that can
+// touch the box has s in [r[0], r[1]] and t in [r[2], r[3]].  Orthographic (camera_orthographic.go:24-46): the ray
+// through (s, t) starts at from + u * fov_w * (s - 0.5) + v * fov_h * (t - 0.5) and runs along -w, so a world point lies
+// on exactly the ray whose (s, t) are its u / v coordinates.  Pinhole (camera_pinhole.go:20-34): the ray from `origin`
+// through llc + s * horizontal + t * vertical; a point in front of the camera is solved for (s, t).  The other cameras
+// (lens, distortion) have no such image.
+struct Projector {
+    const DCamera* cam = nullptr;
     double inv[3][3] = {};
-    if (cam.kind == RT_CAM_PINHOLE) {  // columns of M: llc - origin, horizontal, vertical; P - origin = M * (l, l*s, l*t)
-        double m[3][3];
-        for (int r = 0; r < 3; r++) { m[r][0] = cam.llc[r] - cam.origin[r]; m[r][1] = cam.horizontal[r]; m[r][2] = cam.vertical[r]; }
+    bool init(const DCamera& c) {
+        cam = &c;
+        if (c.kind == RT_CAM_ORTHOGRAPHIC) return c.fov_w > 0 && c.fov_h > 0;
+        if (c.kind != RT_CAM_PINHOLE) return false;
+        double m[3][3];  // columns: llc - origin, horizontal, vertical; P - origin = M * (l, l * s, l * t)
+        for (int r = 0; r < 3; r++) { m[r][0] = c.llc[r] - c.origin[r]; m[r][1] = c.horizontal[r]; m[r][2] = c.vertical[r]; }
         const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
                            m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
         if (!(std::fabs(det) > 0) || !std::isfinite(det)) return false;
         inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det; inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
         inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det; inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
         inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det; inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
-    } else if (!(cam.fov_w > 0) || !(cam.fov_h > 0)) {
-        return false;
+        return true;
     }
-    const size_t n_nodes = sc->node_box.size() / 6;
-    for (size_t i = 0; i < n_nodes; i++) {
-        const double* b = &sc->node_box[i * 6];
-        for (int k = 0; k < 6; k++)
-            if (!std::isfinite(b[k])) return false;
+    // false: the box has no bounded image (not finite, or a corner beside or behind a pinhole camera)
+    bool box(const double lo[3], const double hi[3], double r[4]) const {
+        double lo_s = 1e300, hi_s = -1e300, lo_t = 1e300, hi_t = -1e300;
         for (int c = 0; c < 8; c++) {
-            const double p[3] = {b[(c & 1) ? 3 : 0], b[(c & 2) ? 4 : 1], b[(c & 4) ? 5 : 2]};
+            const double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
             double s, t;
-            if (cam.kind == RT_CAM_ORTHOGRAPHIC) {
+            if (cam->kind == RT_CAM_ORTHOGRAPHIC) {
                 double du = 0, dv = 0;
-                for (int k = 0; k < 3; k++) { du += (p[k] - cam.from[k]) * cam.u[k]; dv += (p[k] - cam.from[k]) * cam.v[k]; }
-                s = 0.5 + du / cam.fov_w;
-                t = 0.5 + dv / cam.fov_h;
+                for (int k = 0; k < 3; k++) { du += (p[k] - cam->from[k]) * cam->u[k]; dv += (p[k] - cam->from[k]) * cam->v[k]; }
+                s = 0.5 + du / cam->fov_w;
+                t = 0.5 + dv / cam->fov_h;
             } else {
                 double x[3] = {0, 0, 0};
-                for (int r = 0; r < 3; r++)
-                    for (int k = 0; k < 3; k++) x[r] += inv[r][k] * (p[k] - cam.origin[k]);
-                if (!(x[0] > 1e-9)) return false;  // beside or behind the camera: its image is unbounded
+                for (int r2 = 0; r2 < 3; r2++)
+                    for (int k = 0; k < 3; k++) x[r2] += inv[r2][k] * (p[k] - cam->origin[k]);
+                if (!(x[0] > 1e-9)) return false;
                 s = x[1] / x[0];
                 t = x[2] / x[0];
             }
@@ -174,10 +172,62 @@ bool screen_bounds(const rt_scene* sc, const DCamera& cam, double out[4]) {
             lo_s = std::min(lo_s, s); hi_s = std::max(hi_s, s);
             lo_t = std::min(lo_t, t); hi_t = std::max(hi_t, t);
         }
+        // generous against the rounding above and in Camera.Cast: a millionth of the frame plus a millionth of the extent
+        const double ms = 1e-6 * (1.0 + std::fabs(lo_s) + std::fabs(hi_s)), mt = 1e-6 * (1.0 + std::fabs(lo_t) + std::fabs(hi_t));
+        r[0] = lo_s - ms; r[1] = hi_s + ms; r[2] = lo_t - mt; r[3] = hi_t + mt;
+        return true;
     }
-    // generous against the rounding above and in Camera.Cast: a millionth of the frame plus a millionth of the extent
-    const double ms = 1e-6 * (1.0 + std::fabs(lo_s) + std::fabs(hi_s)), mt = 1e-6 * (1.0 + std::fabs(lo_t) + std::fabs(hi_t));
-    out[0] = lo_s - ms; out[1] = hi_s + ms; out[2] = lo_t - mt; out[3] = hi_t + mt;  // no nodes: an empty interval, nothing is visible
+};
+
+// Which 8x8 pixel blocks of the image (block (bx, by) = columns 8 bx .., image rows 8 by .., row 0 = top) can see
+// anything of the scene.  Every node's padded bounds are projected; an untransformed mesh is followed down its fast
+// tree until a box covers no more than a few blocks, so the map follows the mesh's outline, not just its bounds.
+// Conservative throughout (padded boxes, one extra pixel, outward rounding): a block left unmarked cannot be reached
+// by any camera ray.  Returns false when there is no such map (see Projector); then nothing is culled.
+struct Occupancy {
+    int bw = 0, bh = 0, dx = 0, dy = 0;
+    std::vector<uint8_t> seen;
+    void mark(const double r[4]) {
+        auto px = [](double v) { return (int64_t)std::max(-1.0e9, std::min(1.0e9, v)); };
+        const int64_t x0 = px(std::floor(r[0] * dx) - 1), x1 = px(std::ceil(r[1] * dx) + 1);
+        const int64_t y0 = px(std::floor(r[2] * dy) - 1), y1 = px(std::ceil(r[3] * dy) + 1);  // counted upward, as the reference's y
+        const int64_t row0 = (int64_t)dy - 1 - y1, row1 = (int64_t)dy - 1 - y0;
+        const int64_t bx0 = std::max<int64_t>(0, x0 >> 3), bx1 = std::min<int64_t>(bw - 1, x1 >> 3);
+        const int64_t by0 = std::max<int64_t>(0, row0 >> 3), by1 = std::min<int64_t>(bh - 1, row1 >> 3);
+        for (int64_t by = by0; by <= by1; by++)
+            for (int64_t bx = bx0; bx <= bx1; bx++) seen[(size_t)(by * bw + bx)] = 1;
+    }
+    bool small(const double r[4]) const { return (r[1] - r[0]) * dx <= 16.0 && (r[3] - r[2]) * dy <= 16.0; }
+};
+
+bool build_occupancy(const rt_scene* sc, const DCamera& cam, int dx, int dy, Occupancy& occ) {
+    Projector proj;
+    if (!proj.init(cam)) return false;
+    occ.dx = dx; occ.dy = dy;
+    occ.bw = (dx + 7) / 8; occ.bh = (dy + 7) / 8;
+    occ.seen.assign((size_t)occ.bw * occ.bh, 0);
+    std::vector<int32_t> stack;
+    for (size_t i = 0; i < sc->nodes.size(); i++) {
+        const double* nb = &sc->node_box[i * 6];
+        double r[4];
+        if (!proj.box(nb, nb + 3, r)) return false;
+        if (sc->nodes[i].kind != RT_SHAPE_MESH) { occ.mark(r); continue; }
+        const DMesh& m = sc->meshes[(size_t)sc->nodes[i].index];
+        const FastNode* nodes = sc->fast_nodes.data() + m.fast_off;
+        stack.assign(1, 0);
+        while (!stack.empty()) {
+            const FastNode& n = nodes[stack.back()];
+            stack.pop_back();
+            for (int k = 0; k < 2; k++) {
+                if (n.child[k] == kFastEmpty) continue;
+                double lo[3], hi[3];
+                for (int a = 0; a < 3; a++) { lo[a] = (double)n.b[k][a][0] + m.center[a]; hi[a] = (double)n.b[k][a][1] + m.center[a]; }
+                if (!proj.box(lo, hi, r)) return false;
+                if (n.child[k] < 0 || occ.small(r)) occ.mark(r);
+                else stack.push_back(n.child[k]);
+            }
+        }
+    }
     return true;
 }
 
@@ -216,12 +266,12 @@ struct EventPool {  // HIP-event timing of the traversal launches, on the stream
 };
 
 // Turns the pilot pass's per-tile costs into the work order of the 8 queues.
-// Where the tiles of a pass lie in the image, and the pixel columns / rows (rows counted upward, as the reference's y,
-// render.go:195) outside which nothing of the scene can be seen (the full int32 range: no such bounds).
+// Where the tiles of a pass lie in the image, and the map of the blocks that can see something of the scene (null: no
+// such map, every tile is traced).
 struct TileGeometry {
     int32_t dx, dy, groups_x, local_rows, band_rank, band_world;
-    int32_t cull_x[2], cull_y[2];
-    // Live pixels of tile t (k_primary's numbering) and whether all of them lie outside the bounds.
+    const Occupancy* occ;
+    // Live pixels of tile t (k_primary's numbering) and whether none of them can see anything.
     bool outside(int64_t t, uint32_t& live_pixels) const {
         const int64_t group = t >> 6;
         const int w = (int)(t & 63);
@@ -231,9 +281,8 @@ struct TileGeometry {
         const int cols = std::max(0, std::min(8, dx - tile_x));
         const int rows = std::max(0, std::min(8, std::min(local_rows - tile_y, dy - row0)));
         live_pixels = (uint32_t)(cols * rows);
-        if (live_pixels == 0) return false;  // outside the frame: the kernel skips it anyway
-        const int y_hi = dy - 1 - row0, y_lo = y_hi - (rows - 1);
-        return tile_x + cols - 1 < cull_x[0] || tile_x > cull_x[1] || y_hi < cull_y[0] || y_lo > cull_y[1];
+        if (live_pixels == 0 || !occ) return false;  // outside the frame: the kernel skips it anyway
+        return occ->seen[(size_t)(row0 >> 3) * occ->bw + (size_t)(tile_x >> 3)] == 0;  // tile_x and row0 are multiples of 8
     }
 };
 
@@ -344,19 +393,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     pass.seed_lo = (uint32_t)((uint64_t)o->seed & 0xffffffffu);
     pass.seed_hi = (uint32_t)((uint64_t)o->seed >> 32);
     pass.max_depth = o->max_ray_depth;
-    TileGeometry geo{};  // filled below, once groups_x / local_rows are known
-    {   // screen bounds in whole pixels, one more on every side than the (s, t) bounds give
-        double sb[4];
-        geo.cull_x[0] = geo.cull_y[0] = INT32_MIN;
-        geo.cull_x[1] = geo.cull_y[1] = INT32_MAX;
-        if (std::getenv("RT_NO_PIXEL_CULL") == nullptr && screen_bounds(sc, cam, sb)) {
-            auto clamp_px = [](double v) { return (int32_t)std::max(-1.0e9, std::min(1.0e9, v)); };
-            geo.cull_x[0] = clamp_px(std::floor(sb[0] * o->dx) - 1);
-            geo.cull_x[1] = clamp_px(std::ceil(sb[1] * o->dx) + 1);
-            geo.cull_y[0] = clamp_px(std::floor(sb[2] * o->dy) - 1);
-            geo.cull_y[1] = clamp_px(std::ceil(sb[3] * o->dy) + 1);
-        }
-    }
+    const bool want_cull = std::getenv("RT_NO_PIXEL_CULL") == nullptr;
     const int64_t tiles_total = (int64_t)pass.groups_x * ((local_rows + 63) / 64) * 64;  // whole groups; tiles outside the image idle
     const int s_first = o->sample_count > 0 ? o->sample_begin : 0;
     const int s_end = o->sample_count > 0 ? o->sample_begin + o->sample_count : o->rays_per_pixel;
@@ -382,9 +419,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
 
     // Cost-ordered schedule: worth a pilot pass when the frame has many tiles and more than a few samples.
     const std::string order_key = std::string(reinterpret_cast<const char*>(camera), sizeof(*camera)) + "|" + std::to_string(o->dx) + "x" +
-                                  std::to_string(o->dy) + "|" + std::to_string(rank) + "/" + std::to_string(world) + "|" + std::to_string(o->mode) + "|" +
-                                  std::to_string(geo.cull_x[0]) + ":" + std::to_string(geo.cull_x[1]) + ":" + std::to_string(geo.cull_y[0]) + ":" +
-                                  std::to_string(geo.cull_y[1]);
+                                  std::to_string(o->dy) + "|" + std::to_string(rank) + "/" + std::to_string(world) + "|" + std::to_string(o->mode) + (want_cull ? "|c" : "|a");
     const bool want_order = tiles_total >= 2048 && std::getenv("RT_NO_TILE_ORDER") == nullptr;
     if (want_order && (w.order_tiles != (size_t)tiles_total || !w.tile_cost)) {
         if (w.tile_cost) (void)hipFree(w.tile_cost);
@@ -507,8 +542,13 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             }
         }
         if (pilot) {
-            geo.dx = o->dx; geo.dy = o->dy; geo.groups_x = pass.groups_x; geo.local_rows = pass.local_rows;
-            geo.band_rank = pass.band_rank; geo.band_world = pass.band_world;
+            Occupancy occ;
+            TileGeometry geo{o->dx, o->dy, pass.groups_x, pass.local_rows, pass.band_rank, pass.band_world, nullptr};
+            const auto t_occ = std::chrono::steady_clock::now();
+            if (want_cull && build_occupancy(sc, cam, o->dx, o->dy, occ)) geo.occ = &occ;
+            if (std::getenv("RT_DEBUG"))
+                fprintf(stderr, "[rt] occupancy map: %s, %.2f ms\n", geo.occ ? "built" : "none",
+                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_occ).count());
             if (int rc = build_tile_order(w, tiles_total, geo, stream)) return rc;
             w.order_key = order_key;
             w.order_valid = true;

@@ -414,6 +414,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HIP_TRY(sc->mem.upload(lights, &dev.lights));
     HIP_TRY(sc->mem.upload(node_box, &dev.node_box));
     sc->node_box = node_box;
+    sc->nodes = nodes;
+    sc->meshes = meshes;
+    sc->fast_nodes = fast_nodes;
     sc->all_terminal = true;
     for (const rt_material& m : materials)
         if (m.kind != RT_MAT_EMITTER && m.kind != RT_MAT_DEBUG_UV && m.kind != RT_MAT_DEBUG_NORMAL) sc->all_terminal = false;
