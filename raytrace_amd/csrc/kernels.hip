@@ -40,6 +40,12 @@ extern __shared__ int32_t dyn_lds[];
 #ifndef RT_PACKET_SHADE_WAVES
 #define RT_PACKET_SHADE_WAVES 4  // ... and when that kernel also runs Material.Resolve
 #endif
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 3  // k_trace
+#endif
+#ifndef RT_DIRECT_WAVES
+#define RT_DIRECT_WAVES 3  // k_direct
+#endif
 #ifndef RT_FAST_WAVES
 #define RT_FAST_WAVES 3
 #endif
@@ -596,7 +602,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
 }
 
 template <int MODE, bool MESH_ONLY>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_trace(DScene sc, PassDesc pass, Queues q, int in, uint32_t n, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_TRACE_WAVES : 2) k_trace(DScene sc, PassDesc pass, Queues q, int in, uint32_t n, double* __restrict__ film) {
     const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = i < n;
     const RayQ& rays = q.rays[in];
@@ -627,7 +633,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WA
 // ComputeDirectLighting's loop body for one (surface point, light) pair
 // (material_lambertian.go:23-52, material_metal.go:68-106, material_dielectric.go:128-170).
 template <int MODE>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_FAST_WAVES : 2) k_direct(DScene sc, Queues q, uint32_t n_surf, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_WAVES : 2) k_direct(DScene sc, Queues q, uint32_t n_surf, double* __restrict__ film) {
     const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = i < n_surf;
     {
