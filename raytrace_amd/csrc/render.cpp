@@ -152,6 +152,17 @@ struct Projector {
     // false: the box has no bounded image (not finite, or a corner beside or behind a pinhole camera)
     bool box(const double lo[3], const double hi[3], double r[4]) const {
         double lo_s = 1e300, hi_s = -1e300, lo_t = 1e300, hi_t = -1e300;
+        if (cam->kind == RT_CAM_ORTHOGRAPHIC) {  // a linear map: the image of the box is the image of its centre +- the sum over the axes
+            double cs = 0, ct = 0, hs = 0, ht = 0;
+            for (int k = 0; k < 3; k++) {
+                const double c = 0.5 * (lo[k] + hi[k]) - cam->from[k], h = 0.5 * (hi[k] - lo[k]);
+                cs += c * cam->u[k]; ct += c * cam->v[k];
+                hs += std::fabs(cam->u[k]) * h; ht += std::fabs(cam->v[k]) * h;
+            }
+            if (!std::isfinite(cs) || !std::isfinite(ct) || !std::isfinite(hs) || !std::isfinite(ht)) return false;
+            lo_s = 0.5 + (cs - hs) / cam->fov_w; hi_s = 0.5 + (cs + hs) / cam->fov_w;
+            lo_t = 0.5 + (ct - ht) / cam->fov_h; hi_t = 0.5 + (ct + ht) / cam->fov_h;
+        } else
         for (int c = 0; c < 8; c++) {
             const double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
             double s, t;
