@@ -368,6 +368,36 @@ typedef struct rt_bvh_info {
 } rt_bvh_info;
 int rt_scene_bvh_info(const rt_scene* scene, uint64_t mesh_index, rt_bvh_info* out);
 
+/* ---- OBJ geometry scanner (host code; needs neither a GPU nor rt_init) ------------------------------------------
+ * The statements obj.ParseFS reads (obj/obj.go:236-468): v, vt, vn, f, usemtl, mtllib, in one pass over the text of a
+ * .obj file, for scans of millions of lines.  Indices are resolved as parseIndex / resolveIndex do (obj.go:359-439:
+ * 1-based, negative = from the end, 0 = absent).  Faces keep their corners (no triangulation: node.go:121-150 fans
+ * them later).  The scanner reads only the well-formed subset; at the first line it is not sure to read like the
+ * reference's line parser it stops and sets fallback_line (1-based): the caller must then run the line parser over the
+ * whole text, so errors and corner cases are the line parser's.  usemtl / mtllib arguments are returned as byte
+ * ranges of the text, in order of appearance. */
+enum rt_obj_event_kind { RT_OBJ_USEMTL = 0, RT_OBJ_MTLLIB = 1 };
+typedef struct rt_obj_event {
+    int32_t kind;        /* rt_obj_event_kind */
+    uint32_t line;       /* 1-based line number */
+    uint64_t line_off, line_len; /* the statement without surrounding white space */
+    uint64_t arg_off, arg_len;   /* what follows the first blank */
+} rt_obj_event;
+typedef struct rt_obj_scan {
+    uint64_t n_vertices, n_texcoords, n_normals, n_faces, n_corners, n_events;
+    const double* vertices;      /* 3 per vertex  (obj.go:270-290) */
+    const double* texcoords;     /* 2 per entry   (obj.go:293-309) */
+    const double* normals;       /* 3 per normal  (obj.go:312-332) */
+    const int32_t* corners;      /* 3 per corner: vertex, texcoord, normal index */
+    const uint64_t* face_start;  /* n_faces + 1 offsets into corners (in corners, not ints) */
+    const int32_t* face_event;   /* per face: index of the usemtl event in force, -1 = none yet */
+    const rt_obj_event* events;
+    uint64_t fallback_line;      /* 0 = the whole text was read */
+    void* owner;                 /* storage of the arrays; release with rt_obj_scan_free */
+} rt_obj_scan;
+int rt_obj_scan_text(const char* text, uint64_t len, rt_obj_scan* out);
+void rt_obj_scan_free(rt_obj_scan* scan);
+
 #ifdef __cplusplus
 }
 #endif

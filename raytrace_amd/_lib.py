@@ -10,7 +10,7 @@ _PATH = os.environ.get("RT_LIB_PATH") or os.path.join(os.path.dirname(os.path.ab
 
 SYMBOLS = [
     "rt_apply_filter", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
-    "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info",
+    "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info", "rt_obj_scan_text", "rt_obj_scan_free",
 ]
 
 
@@ -61,6 +61,10 @@ def open_library() -> C.CDLL:
     lib.rt_apply_filter.restype = C.c_int
     lib.rt_scene_bvh_info.argtypes = [C.c_void_p, C.c_uint64, P(abi.BvhInfo)]
     lib.rt_scene_bvh_info.restype = C.c_int
+    lib.rt_obj_scan_text.argtypes = [C.c_char_p, C.c_uint64, P(abi.ObjScan)]
+    lib.rt_obj_scan_text.restype = C.c_int
+    lib.rt_obj_scan_free.argtypes = [P(abi.ObjScan)]
+    lib.rt_obj_scan_free.restype = None
     return lib
 
 
@@ -81,3 +85,20 @@ def load(device: int = None) -> C.CDLL:
         check(lib.rt_init(ids, 1), lib)
         _LIB = lib
     return _LIB
+
+
+_HOST_LIB = None
+
+
+def host_library():
+    """The library for its host-only entry points (rt_obj_scan_text): opened, not initialised, no GPU needed.
+    None when it cannot be opened (not built, no HIP runtime on this machine)."""
+    global _HOST_LIB
+    if _LIB is not None:
+        return _LIB
+    if _HOST_LIB is None:
+        try:
+            _HOST_LIB = open_library()
+        except (RuntimeError, OSError):
+            _HOST_LIB = False
+    return _HOST_LIB or None

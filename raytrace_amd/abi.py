@@ -156,3 +156,19 @@ HIT_DTYPE = [
     ("node", "<i4"), ("prim", "<i4"), ("t", "<f8"), ("at", "<f8", (3,)), ("normal", "<f8", (3,)),
     ("uv", "<f8", (2,)), ("boxes_tested", "<u4"), ("prims_tested", "<u4"),
 ]
+
+
+class ObjEvent(C.Structure):  # rt_obj_event
+    _fields_ = [("kind", C.c_int32), ("line", C.c_uint32), ("line_off", C.c_uint64), ("line_len", C.c_uint64),
+                ("arg_off", C.c_uint64), ("arg_len", C.c_uint64)]
+
+
+class ObjScan(C.Structure):  # rt_obj_scan
+    _fields_ = [("n_vertices", C.c_uint64), ("n_texcoords", C.c_uint64), ("n_normals", C.c_uint64), ("n_faces", C.c_uint64),
+                ("n_corners", C.c_uint64), ("n_events", C.c_uint64),
+                ("vertices", C.POINTER(C.c_double)), ("texcoords", C.POINTER(C.c_double)), ("normals", C.POINTER(C.c_double)),
+                ("corners", C.POINTER(C.c_int32)), ("face_start", C.POINTER(C.c_uint64)), ("face_event", C.POINTER(C.c_int32)),
+                ("events", C.POINTER(ObjEvent)), ("fallback_line", C.c_uint64), ("owner", C.c_void_p)]
+
+
+OBJ_USEMTL, OBJ_MTLLIB = 0, 1

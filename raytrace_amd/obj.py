@@ -67,6 +67,66 @@ class Object:  # obj.go:148-154
     Materials: Dict[str, Material] = field(default_factory=dict)
 
 
+class FaceTable:
+    """The faces of a large object as arrays instead of a list of Face objects: what the native scanner
+    (rt_obj_scan_text) returns.  Reads like the list it stands for (len, indexing, iteration give Face objects, made on
+    demand); the converters of phys.py use the arrays directly."""
+
+    def __init__(self, corners: np.ndarray, start: np.ndarray, material_id: np.ndarray, material_names: List[str]):
+        self.corners = corners          # (n_corners, 3) int32: vertex, texcoord, normal index, 1-based, 0 = not given
+        self.start = start              # (n_faces + 1,) int64 offsets into corners
+        self.material_id = material_id  # (n_faces,) int32 index into material_names, -1 = ""
+        self.material_names = material_names
+
+    def __len__(self):
+        return len(self.material_id)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        c = self.corners[self.start[i]:self.start[i + 1]]
+        m = int(self.material_id[i])
+        return Face([(int(a), int(b), int(d)) for a, b, d in c], self.material_names[m] if m >= 0 else "")
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def groups(self) -> Dict[str, np.ndarray]:
+        """Material name ("default" for none) -> indices of its faces, names in order of first use."""
+        out: Dict[str, np.ndarray] = {}
+        if len(self) == 0:
+            return out
+        ids, first = np.unique(self.material_id, return_index=True)
+        for m in ids[np.argsort(first)]:
+            name = (self.material_names[int(m)] if m >= 0 else "") or "default"
+            sel = np.nonzero(self.material_id == m)[0]
+            out[name] = np.concatenate([out[name], sel]) if name in out else sel
+        for name in out:
+            out[name] = np.sort(out[name])
+        return out
+
+    def fan(self, faces: np.ndarray = None) -> np.ndarray:
+        """(n_triangles, 3, 3) indices: every face (or the selected ones) cut into a fan around its first corner."""
+        start = self.start[:-1] if faces is None else self.start[faces]
+        count = (self.start[1:] - self.start[:-1]) if faces is None else (self.start[faces + 1] - self.start[faces])
+        ntri = np.maximum(count - 2, 0)
+        total = int(ntri.sum())
+        if total == 0:
+            return np.zeros((0, 3, 3), dtype=np.int64)
+        face_of = np.repeat(np.arange(len(start)), ntri)
+        k = np.arange(total) - np.repeat(np.cumsum(ntri) - ntri, ntri)  # triangle number inside its face
+        base = start[face_of]
+        idx = np.stack([base, base + k + 1, base + k + 2], axis=1)
+        return self.corners[idx].astype(np.int64)
+
+
 class ParseError(ValueError):  # obj.go:157-171
     def __init__(self, filename, line, line_text, msg):
         self.Filename, self.Line, self.LineText, self.Msg = filename, line, line_text, msg
@@ -92,6 +152,9 @@ def ParseFS(fsys, pattern: str) -> Object:  # obj.go:174-195
         data = fsys.read(name)
     except OSError as e:
         raise ParseError(name, 0, "", f"failed to read file '{pattern}': {e}")
+    fast = _scan_native(data, fsys, name)
+    if fast is not None:
+        return fast
     obj = Object()
     current_material = ""
     text = data.decode("utf-8", errors="replace")
@@ -151,6 +214,68 @@ def ParseFS(fsys, pattern: str) -> Object:  # obj.go:174-195
                     raise err(f"failed to read material library '{base}': {e}")
                 _parse_mtl(mtl.decode("utf-8", errors="replace"), base, obj)
     return obj
+
+
+def _scan_native(data: bytes, fsys, name: str):
+    """The same object through the library's scanner (rt_obj_scan_text), arrays instead of lists; None when the library is
+    not available or the scanner met a line it leaves to the line parser above (then that parser reads the whole file,
+    so every error and corner case is its own).  RT_OBJ_NATIVE=0 switches the scanner off."""
+    if os.environ.get("RT_OBJ_NATIVE", "1") == "0" or len(data) < _NATIVE_MIN_BYTES:
+        return None
+    from . import _lib, abi
+    import ctypes as C
+    lib = _lib.host_library()
+    if lib is None:
+        return None
+    scan = abi.ObjScan()
+    if lib.rt_obj_scan_text(data, len(data), C.byref(scan)) != abi.RT_OK:
+        return None
+    try:
+        if scan.fallback_line != 0:
+            return None
+
+        def arr(ptr, n, width, dtype):
+            if n == 0:
+                return np.zeros((0, width) if width > 1 else (0,), dtype=dtype)
+            a = np.ctypeslib.as_array(ptr, shape=(n * width,)).astype(dtype, copy=True)
+            return a.reshape(n, width) if width > 1 else a
+
+        obj = Object()
+        obj.Vertices = arr(scan.vertices, scan.n_vertices, 3, np.float64)
+        obj.TexCoords = arr(scan.texcoords, scan.n_texcoords, 2, np.float64)
+        obj.Normals = arr(scan.normals, scan.n_normals, 3, np.float64)
+        corners = arr(scan.corners, scan.n_corners, 3, np.int32)
+        start = arr(scan.face_start, scan.n_faces + 1, 1, np.int64)
+        face_event = arr(scan.face_event, scan.n_faces, 1, np.int32)
+        names: List[str] = []
+        event_name = np.full(scan.n_events + 1, -1, dtype=np.int32)  # last slot: faces before any usemtl
+        libs = []
+        for i in range(scan.n_events):
+            ev = scan.events[i]
+            arg = data[ev.arg_off:ev.arg_off + ev.arg_len].decode("utf-8", errors="replace")
+            if ev.kind == abi.OBJ_USEMTL:
+                if arg not in names:
+                    names.append(arg)
+                event_name[i] = names.index(arg)
+            else:
+                libs.append((int(ev.line), data[ev.line_off:ev.line_off + ev.line_len].decode("utf-8", errors="replace"), arg))
+        obj.Faces = FaceTable(corners, start, event_name[face_event], names)
+    finally:
+        lib.rt_obj_scan_free(C.byref(scan))
+    for line_no, line, rest in libs:  # obj.go:451-468
+        for filename in rest.split():
+            base = posixpath.basename(filename)
+            try:
+                mtl = fsys.read(base)
+            except OSError as e:
+                raise ParseError(name, line_no, line, f"failed to read material library '{base}': {e}")
+            _parse_mtl(mtl.decode("utf-8", errors="replace"), base, obj)
+    return obj
+
+
+# Files smaller than this are read by the line parser: its lists of tuples are what small callers and the reference's
+# own test tables expect, and the scanner only pays off on large files.
+_NATIVE_MIN_BYTES = 1 << 16
 
 
 def _parse_index(s: str, obj: Object) -> Tuple[int, int, int]:  # obj.go:359-428

@@ -930,16 +930,19 @@ def _faces_of(src, faces) -> np.ndarray:
     """Fan triangulation + vertex lookup + Face.Validate filtering (node.go:121-150, 172-193): (n, 3, 5) float64."""
     pos = np.asarray(src.Vertices, dtype=np.float64).reshape(-1, 3)
     tex = np.asarray(src.TexCoords, dtype=np.float64).reshape(-1, 2)
-    tri = []
-    for face in faces:
-        idx = face.Indices
-        if len(idx) < 3:
-            continue
-        for i in range(1, len(idx) - 1):
-            tri.append((idx[0], idx[i], idx[i + 1]))
-    if not tri:
+    if isinstance(faces, tuple):  # (FaceTable, indices of the faces wanted or None): the arrays of the native scanner
+        t = faces[0].fan(faces[1])
+    else:
+        tri = []
+        for face in faces:
+            idx = face.Indices
+            if len(idx) < 3:
+                continue
+            for i in range(1, len(idx) - 1):
+                tri.append((idx[0], idx[i], idx[i + 1]))
+        t = np.asarray(tri, dtype=np.int64).reshape(-1, 3, 3)  # (n, 3 corners, (v, vt, vn))
+    if len(t) == 0:
         return np.zeros((0, 3, 5))
-    t = np.asarray(tri, dtype=np.int64)  # (n, 3 corners, (v, vt, vn))
     v = t[..., 0] - 1
     if (v < 0).any() or (v >= len(pos)).any():
         raise ValueError("vertex index out of range")
@@ -960,7 +963,8 @@ def _faces_of(src, faces) -> np.ndarray:
 
 
 def ConvertObjectToShape(src) -> Mesh:  # node.go:195-232
-    return Mesh(_faces_of(src, src.Faces))
+    from . import obj as _obj
+    return Mesh(_faces_of(src, (src.Faces, None) if isinstance(src.Faces, _obj.FaceTable) else src.Faces))
 
 
 def ConvertObjectToMaterial(src, asset_fs) -> dict:  # node.go:266-309
@@ -985,9 +989,13 @@ def ConvertObjectToNodes(src, asset_fs) -> list:  # node.go:101-169
     """One Mesh node per material name.  The reference iterates a Go map, so its node order is unspecified;
     here nodes come in order of first use, which is stable."""
     materials = ConvertObjectToMaterial(src, asset_fs)
+    from . import obj as _obj
     groups: dict = {}
-    for face in src.Faces:
-        groups.setdefault(face.Material or "default", []).append(face)
+    if isinstance(src.Faces, _obj.FaceTable):
+        groups = {name: (src.Faces, sel) for name, sel in src.Faces.groups().items()}
+    else:
+        for face in src.Faces:
+            groups.setdefault(face.Material or "default", []).append(face)
     nodes = []
     for name, faces in groups.items():
         mesh = NewMesh(_faces_of(src, faces))

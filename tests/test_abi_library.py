@@ -30,7 +30,8 @@ def library():
 def test_header_declares_the_entry_points():
     names = declared_functions()
     for must in ("rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
-                 "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info"):
+                 "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info", "rt_obj_scan_text",
+                 "rt_obj_scan_free"):
         assert must in names, must
 
 
@@ -48,7 +49,8 @@ def test_struct_sizes_match_the_header():
              ("rt_face", abi.Face), ("rt_mesh", abi.Mesh), ("rt_transformed", abi.Transformed), ("rt_image", abi.Image),
              ("rt_texture", abi.Texture), ("rt_material", abi.Material), ("rt_light", abi.Light), ("rt_node", abi.Node),
              ("rt_scene_desc", abi.SceneDesc), ("rt_camera_desc", abi.CameraDesc), ("rt_render_opts", abi.RenderOpts),
-             ("rt_stats", abi.Stats), ("rt_hit", abi.Hit), ("rt_bvh_info", abi.BvhInfo)]
+             ("rt_stats", abi.Stats), ("rt_hit", abi.Hit), ("rt_bvh_info", abi.BvhInfo), ("rt_obj_event", abi.ObjEvent),
+             ("rt_obj_scan", abi.ObjScan)]
     src = '#include <stdio.h>\n#include "rt_hip.h"\nint main(void){' + "".join(
         f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n"
     with tempfile.TemporaryDirectory() as d:

@@ -204,3 +204,91 @@ def test_reference_capsule_fixture_parses():
     assert sum(len(n.Shape.Face) for n in nodes) <= 10000
     for n in nodes:
         n.Validate()
+
+
+# ---- native scanner (rt_obj_scan_text) against the line parser -----------------------------------------------------
+
+
+def _both_ways(files, name, monkeypatch):
+    """Parse with the native scanner forced on (any size) and with it off; returns (native, lines)."""
+    monkeypatch.setattr(obj, "_NATIVE_MIN_BYTES", 0)
+    monkeypatch.setenv("RT_OBJ_NATIVE", "1")
+    a = obj.ParseFS(obj.MapFS(files), name)
+    monkeypatch.setenv("RT_OBJ_NATIVE", "0")
+    b = obj.ParseFS(obj.MapFS(files), name)
+    return a, b
+
+
+def _same_object(a, b):
+    for x, y, w in ((a.Vertices, b.Vertices, 3), (a.TexCoords, b.TexCoords, 2), (a.Normals, b.Normals, 3)):
+        assert np.array_equal(np.asarray(x, dtype=np.float64).reshape(-1, w), np.asarray(y, dtype=np.float64).reshape(-1, w), equal_nan=True)
+    assert list(a.Faces) == list(b.Faces)
+    assert a.Materials == b.Materials
+
+
+def test_native_scanner_is_used_and_agrees_with_the_line_parser(monkeypatch):
+    text = "\n".join([
+        "# a comment", "", "mtllib a.mtl b.mtl", "o thing", "g group one",
+        "v 0 0 0", "v 1 0 0", "v 1 1 0", "v 0 1 0", "v 0.5 0.5 1e0", "v -1.5e-3 +2.25 .5", "  v 3. 4 5  \r",
+        "vt 0 0", "vt 1 0", "vt 1 1", "vt 0.25 0.75",
+        "vn 0 0 1", "vn 0 1 0",
+        "f 1 2 3", "usemtl red", "f 1/1 2/2 3/3 4/4", "f 1//1 2//1 5//2", "f 1/1/1 2/2/1   5/3/2",
+        "usemtl blue stuff", "f -1 -2 -3", "f -7/-4/-2 2/2/-1 3/3/1 4/4/1 5/1/1",
+        "usemtl red", "f 7 6 5", "s off", "lonetoken", "unknown directive here",
+    ]) + "\n"
+    files = {"m.obj": text, "a.mtl": "newmtl red\nKd 1 0 0\n", "b.mtl": "newmtl blue stuff\nKd 0 0 1\nmap_Kd t.png\n"}
+    a, b = _both_ways(files, "m.obj", monkeypatch)
+    assert isinstance(a.Faces, obj.FaceTable) and isinstance(b.Faces, list)
+    _same_object(a, b)
+    assert len(a.Faces) == 7 and a.Faces[2].Material == "red" and a.Faces[-1].Indices == [(7, 0, 0), (6, 0, 0), (5, 0, 0)]
+    # the converters take the arrays directly and give the same meshes, node for node
+    for name, sel in a.Faces.groups().items():
+        want = phys._faces_of(b, [f for f in b.Faces if (f.Material or "default") == name])
+        assert np.array_equal(phys._faces_of(a, (a.Faces, sel)), want), name
+    assert np.array_equal(phys.ConvertObjectToShape(a).Face, phys.ConvertObjectToShape(b).Face)
+
+
+@pytest.mark.parametrize("bad", [
+    "v 1 2", "v 1 2 x", "v 1 2 3 4", "v 1  2 3", "vt 1 2 3", "vn 1 2", "f 1 2", "f 1 2 9", "f 1/ 2 3", "f 1/1/1/1 2 3", "f 0 1 2",
+    "usemtl", "mtllib", "mtllib missing.mtl", "v 1_0 2 3", "v nan 0 0", "v 0x10 0 0", "f 1\t2 3", "v 1 2 3\x0b",
+    "v 1 2 3 # trailing comment", "v 1e400 0 0", "f +1 2 3", "f 1/1 2 3", "\xa0v 1 2 3", "usemtl café",
+])
+def test_lines_the_scanner_leaves_to_the_line_parser_behave_as_before(bad, monkeypatch):
+    """Anything but the well-formed subset: the scanner steps aside, so both ways give the same object or the same error."""
+    text = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n" + bad + "\nf 1 2 3\n"
+    results = []
+    for native in ("1", "0"):
+        monkeypatch.setattr(obj, "_NATIVE_MIN_BYTES", 0)
+        monkeypatch.setenv("RT_OBJ_NATIVE", native)
+        try:
+            results.append(obj.ParseFS(obj.MapFS({"m.obj": text}), "m.obj"))
+        except obj.ParseError as e:
+            results.append((e.Filename, e.Line, e.LineText, e.Msg))
+    if isinstance(results[1], tuple):
+        assert results[0] == results[1]
+    else:
+        _same_object(results[0], results[1])
+
+
+def test_native_scanner_on_a_written_mesh(monkeypatch):
+    """scenes.write_obj -> ParseFS -> ConvertObjectToShape gives the faces back, through the scanner and at its speed."""
+    import time
+    from raytrace_amd import scenes
+    faces = scenes.scan_standin_mesh(5)  # 20480 faces
+    obj_text, mtl_text = scenes.write_obj(faces)
+    files = {"scan.obj": obj_text, "scan.mtl": mtl_text}
+    assert len(obj_text) > obj._NATIVE_MIN_BYTES  # large enough to take the scanner by itself
+    monkeypatch.setenv("RT_OBJ_NATIVE", "1")
+    t0 = time.perf_counter()
+    a = obj.ParseFS(obj.MapFS(files), "scan.obj")
+    t_native = time.perf_counter() - t0
+    assert isinstance(a.Faces, obj.FaceTable)
+    got = phys.ConvertObjectToShape(a).Face
+    keep = np.isfinite(faces).all(axis=(1, 2))
+    assert len(got) == int(keep.sum()) and np.array_equal(got, faces[keep])
+    monkeypatch.setenv("RT_OBJ_NATIVE", "0")
+    t0 = time.perf_counter()
+    b = obj.ParseFS(obj.MapFS(files), "scan.obj")
+    t_lines = time.perf_counter() - t0
+    _same_object(a, b)
+    assert t_native < t_lines
