@@ -3,9 +3,11 @@
 // The reference hands 16x16 tiles to NumCPU goroutines, each of which recurses through
 // tracePath per sample.  Here the image (this process's row bands of it) is cut into passes of
 // at most `q` paths; a pass is one k_primary launch (a persistent grid draining a queue of small pixel blocks) and
-// then, only while some hit needs Material.Resolve, generations of k_shade / k_direct / k_trace.
-// A scene whose materials all just emit (the scan configuration: Emitter + image texture) never
-// leaves k_primary and is rendered without a single host synchronisation per pass.
+// then, only while rays were scattered, generations of k_direct (light loop of the hits just made) / k_trace (the
+// scattered rays, Material.Resolve included).  A scene whose materials all just emit (the scan configuration:
+// Emitter + image texture) never leaves k_primary and is rendered without a single host synchronisation per pass.
+// For orthographic and pinhole cameras the tiles that cannot see any node are left out of the primary launch's
+// schedule (Occupancy below) and their rays counted here.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
