@@ -125,6 +125,7 @@ RT_DEV bool refract(V3 v, V3 n, double ni_over_nt, V3& out) {  // material_diele
 
 struct Scatter {
     V3 emission;
+    V3 albedo;  // Lambertian: the texture value at the hit (the light loop needs it again)
     V3 dir[2];
     V3 rad[2];
     int n;
@@ -139,7 +140,8 @@ RT_DEV void resolve(const DScene& sc, const rt_material& m, V3 d, V3 in_rad, con
         case RT_MAT_LAMBERTIAN: {  // material_lambertian.go:59-81
             V3 n = unit(c.normal);
             out.dir[0] = cosine_weighted_hemisphere(rng, n);
-            out.rad[0] = in_rad * texture_at(sc, m.texture, c.u, c.v);
+            out.albedo = texture_at(sc, m.texture, c.u, c.v);
+            out.rad[0] = in_rad * out.albedo;
             out.n = 1;
             break;
         }

@@ -372,7 +372,7 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
             want_surf = true;
             s_n = unit(c.normal);
             s_wo = unit(r.d * -1.0);  // s.outgoing.Unit() (material_metal.go:59)
-            if (m.kind == RT_MAT_LAMBERTIAN) s_alb = texture_at(sc, m.texture, c.u, c.v);
+            if (m.kind == RT_MAT_LAMBERTIAN) s_alb = sct.albedo;  // Material.Resolve has just evaluated the texture here
             else if (m.kind == RT_MAT_METAL) s_alb = ld3(m.albedo);
             else if (!(dot(s_wo, s_n) > 0)) { inside = 1; s_n = s_n * -1.0; }  // material_dielectric.go:112-120
         }
