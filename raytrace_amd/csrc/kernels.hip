@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
     uint32_t n_total = 0, n_left = 0;
     // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
     auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
-        const uint32_t item = atomicAdd(&counters->tile_cursor[owner], 1u);
+        const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
         const uint32_t idx = item / n_sub;
         long long cand = -1;
         if (pass.order) {

@@ -134,10 +134,18 @@ struct SurfQ {
 };
 constexpr size_t kSurfBytes = 12 * 8 + 4 * 4;
 
+// Every counter sits in a 128-byte line of its own: atomics on different counters then go to different L2 channels
+// instead of queueing behind one another on a single line (thousands of waves append and tally at the same time).
 struct Counters {
-    unsigned long long total, exceeded, left, shadow;  // RenderStats (render.go:38-45) + occlusion rays
-    unsigned int next_count, surf_count;  // append cursors of the next generation's rays and of the lit surface points
-    unsigned int tile_cursor[8];  // next tile of each XCD's share of a primary launch
+    alignas(128) unsigned long long total;     // RenderStats (render.go:38-45) ...
+    alignas(128) unsigned long long exceeded;
+    alignas(128) unsigned long long left;
+    alignas(128) unsigned long long shadow;    // ... + occlusion rays
+    alignas(128) unsigned int next_count;      // append cursor of the next generation's rays (first of the cursors the host resets)
+    alignas(128) unsigned int surf_count;      // append cursor of the lit surface points
+    struct alignas(128) Cursor {
+        unsigned int v;
+    } tile_cursor[8];                          // next tile of each XCD's share of a primary launch
 };
 
 }  // namespace rt
