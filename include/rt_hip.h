@@ -368,6 +368,24 @@ typedef struct rt_bvh_info {
 } rt_bvh_info;
 int rt_scene_bvh_info(const rt_scene* scene, uint64_t mesh_index, rt_bvh_info* out);
 
+/* The tree NewBVH(shapes, 0) builds over the faces of a mesh (shape_bvh.go:81-272), as a flat array
+ * (host code; needs neither a GPU nor rt_init).  It is what a Mesh carries in its BVH field and what
+ * (*BVH).MarshalJSON writes (shape_bvh.go:275-297), so a host can export a mesh without building the
+ * tree a second time.  Nodes are in depth-first pre-order: the Left child of inner node i is node
+ * i + 1, its Right child node `right`.  A node with count > 0 is a leaf BVH{Left == Right}: it holds
+ * the faces leaf_faces[first .. first + count), in the order of the Group's Shapes (count == 1: the
+ * face itself, no Group, shape_bvh.go:91-97).  nodes has room for node_cap records (2 * n_faces is
+ * always enough), leaf_faces for n_faces indices; *n_nodes receives the number of nodes, also when
+ * node_cap is too small (RT_ERR_INVALID then, nothing written). */
+typedef struct rt_bvh_node {
+    double bounds_min[3], bounds_max[3]; /* BVH.bounds (AABB, shape.go:27-30) */
+    int32_t right;                       /* inner node: index of the Right child; leaf: -1 */
+    int32_t first, count;                /* leaf: range of leaf_faces; inner node: count == 0 */
+    int32_t pad;
+} rt_bvh_node;
+int rt_bvh_build(const rt_face* faces, uint64_t n_faces, rt_bvh_node* nodes, uint64_t node_cap,
+                 int32_t* leaf_faces, uint64_t* n_nodes);
+
 /* ---- OBJ geometry scanner (host code; needs neither a GPU nor rt_init) ------------------------------------------
  * The statements obj.ParseFS reads (obj/obj.go:236-468): v, vt, vn, f, usemtl, mtllib, in one pass over the text of a
  * .obj file, for scans of millions of lines.  Indices are resolved as parseIndex / resolveIndex do (obj.go:359-439:

@@ -11,6 +11,7 @@ _PATH = os.environ.get("RT_LIB_PATH") or os.path.join(os.path.dirname(os.path.ab
 SYMBOLS = [
     "rt_apply_filter", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
     "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info", "rt_obj_scan_text", "rt_obj_scan_free",
+    "rt_bvh_build",
 ]
 
 
@@ -65,6 +66,8 @@ def open_library() -> C.CDLL:
     lib.rt_obj_scan_text.restype = C.c_int
     lib.rt_obj_scan_free.argtypes = [P(abi.ObjScan)]
     lib.rt_obj_scan_free.restype = None
+    lib.rt_bvh_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, P(C.c_uint64)]
+    lib.rt_bvh_build.restype = C.c_int
     return lib
 
 

@@ -158,6 +158,11 @@ HIT_DTYPE = [
 ]
 
 
+BVH_NODE_DTYPE = [  # rt_bvh_node
+    ("bounds_min", "<f8", (3,)), ("bounds_max", "<f8", (3,)), ("right", "<i4"), ("first", "<i4"), ("count", "<i4"), ("pad", "<i4"),
+]
+
+
 class ObjEvent(C.Structure):  # rt_obj_event
     _fields_ = [("kind", C.c_int32), ("line", C.c_uint32), ("line_off", C.c_uint64), ("line_len", C.c_uint64),
                 ("arg_off", C.c_uint64), ("arg_len", C.c_uint64)]

@@ -444,6 +444,27 @@ int rt_scene_bvh_info(const rt_scene* scene, uint64_t mesh_index, rt_bvh_info* o
     return RT_OK;
 }
 
+int rt_bvh_build(const rt_face* faces, uint64_t n_faces, rt_bvh_node* nodes, uint64_t node_cap, int32_t* leaf_faces, uint64_t* n_nodes) {
+    static_assert(sizeof(rt_bvh_node) == sizeof(RefNode), "rt_bvh_node mirrors RefNode");
+    if (!faces || n_faces == 0 || n_faces > (uint64_t)INT32_MAX || !n_nodes) return fail(RT_ERR_INVALID, "bad argument");
+    MeshBvh b;
+    build_mesh_bvh(faces, n_faces, b);
+    *n_nodes = b.ref_nodes.size();
+    if (!nodes || !leaf_faces || node_cap < b.ref_nodes.size()) return fail(RT_ERR_INVALID, "node array too small");
+    for (size_t i = 0; i < b.ref_nodes.size(); i++) {
+        const RefNode& r = b.ref_nodes[i];
+        rt_bvh_node& o = nodes[i];
+        for (int k = 0; k < 3; k++) { o.bounds_min[k] = r.box[k]; o.bounds_max[k] = r.box[3 + k]; }
+        const bool leaf = r.right < 0;
+        o.right = r.right;
+        o.first = leaf ? r.first : 0;
+        o.count = leaf ? r.count : 0;
+        o.pad = 0;
+    }
+    std::memcpy(leaf_faces, b.prim_face.data(), n_faces * sizeof(int32_t));
+    return RT_OK;
+}
+
 void rt_cancel(rt_scene* scene) {
     if (scene) scene->cancel.store(true);
 }

@@ -576,6 +576,15 @@ class Scene:  # scene.go:9-79
             except ValueError as e:
                 raise ValueError(f"bad light {i}: {e}")
 
+    def MarshalJSON(self) -> str:  # scene.go:82-114
+        from . import scene_json
+        return scene_json.MarshalScene(self)
+
+    @staticmethod
+    def UnmarshalJSON(text, strict: bool = False, asset_dir=None) -> "Scene":  # scene.go:117-159
+        from . import scene_json
+        return scene_json.UnmarshalScene(text, strict, asset_dir)
+
 
 @dataclass
 class RenderStats:  # render.go:38-45
