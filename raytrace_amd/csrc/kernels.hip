@@ -293,15 +293,16 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// Adds per-lane tallies to the RenderStats counters, one atomic per wave and counter.
+// Adds per-lane tallies to the RenderStats counters, one atomic per wave and counter, on the stripe of this workgroup.
 RT_DEV void wave_tally(Counters* c, uint32_t total, uint32_t left, uint32_t exceeded) {
     total = wave_sum(total);
     left = wave_sum(left);
     exceeded = wave_sum(exceeded);
     if ((threadIdx.x & 63) == 0) {
-        if (total) atomicAdd(&c->total, (unsigned long long)total);
-        if (left) atomicAdd(&c->left, (unsigned long long)left);
-        if (exceeded) atomicAdd(&c->exceeded, (unsigned long long)exceeded);
+        Counters::Tally& t = c->tally[blockIdx.x & (kTallyStripes - 1)];
+        if (total) atomicAdd(&t.total, (unsigned long long)total);
+        if (left) atomicAdd(&t.left, (unsigned long long)left);
+        if (exceeded) atomicAdd(&t.exceeded, (unsigned long long)exceeded);
     }
 }
 
@@ -310,6 +311,26 @@ RT_DEV void film_add(double* film, uint32_t pixel, V3 v) {
     if (v.x != 0) atomicAdd(f + 0, v.x);
     if (v.y != 0) atomicAdd(f + 1, v.y);
     if (v.z != 0) atomicAdd(f + 2, v.z);
+}
+
+// film_add for a whole wave: runs of neighbouring lanes that name the same pixel are summed with shuffles first
+// and only the first lane of a run issues the atomics.  Queue entries of one pixel's samples lie next to each other
+// (a wave appends its lanes in order), and an atomic on the film is performed at the memory side, beyond the
+// per-XCD L2s, where thousands of waves queue: a run of 16 samples costs 3 of them instead of 48.  Must be reached
+// by all lanes of the wave; a lane with nothing to add passes v = 0 (any pixel).
+RT_DEV void film_add_wave(double* film, uint32_t pixel, V3 v) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t prev = __shfl_up(pixel, 1, 64);
+    const bool head = lane == 0 || prev != pixel;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+    const int after = above ? __ffsll((long long)above) - 1 : 63 - lane;  // lanes of this run that follow this one
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ox = __shfl_down(v.x, off, 64), oy = __shfl_down(v.y, off, 64), oz = __shfl_down(v.z, off, 64);
+        if (off <= after) { v.x += ox; v.y += oy; v.z += oz; }
+    }
+    if (head) film_add(film, pixel, v);
 }
 
 RT_DEV bool terminal_kind(int kind) { return kind == RT_MAT_EMITTER || kind == RT_MAT_DEBUG_UV || kind == RT_MAT_DEBUG_NORMAL; }
@@ -378,18 +399,28 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
         }
     }
     wave_tally(q.counters, n_counted, 0, n_cut);
+    {   // both children of every lane in one reservation: first children first, in lane order, then the second ones
+        const unsigned long long m0 = __ballot(child_ok[0]), m1 = __ballot(child_ok[1]);
+        const int lane = threadIdx.x & 63;
+        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
+        uint32_t base = 0;
+        if (n0 + n1 != 0) {
+            if (lane == 0) base = atomicAdd(&q.counters->next_count, n0 + n1);
+            base = __shfl(base, 0, 64);
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const bool want = child_ok[k];
-        const uint32_t slot = wave_append(&q.counters->next_count, want);
-        if (want && slot < q.ray_capacity) {
-            next.o[0][slot] = at.x; next.o[1][slot] = at.y; next.o[2][slot] = at.z;
-            next.d[0][slot] = sct.dir[k].x; next.d[1][slot] = sct.dir[k].y; next.d[2][slot] = sct.dir[k].z;
-            next.rad[0][slot] = sct.rad[k].x; next.rad[1][slot] = sct.rad[k].y; next.rad[2][slot] = sct.rad[k].z;
-            next.pixel[slot] = ps.pixel;
-            next.sample[slot] = ps.sample;
-            next.path[slot] = ps.path * 2u + (uint32_t)k;
-            next.depth_n[slot] = (depth + 1u) << 24;
+        for (int k = 0; k < 2; k++) {
+            const uint32_t slot = k == 0 ? base + (uint32_t)__popcll(m0 & below) : base + n0 + (uint32_t)__popcll(m1 & below);
+            if (child_ok[k] && slot < q.ray_capacity) {
+                next.o[0][slot] = at.x; next.o[1][slot] = at.y; next.o[2][slot] = at.z;
+                next.d[0][slot] = sct.dir[k].x; next.d[1][slot] = sct.dir[k].y; next.d[2][slot] = sct.dir[k].z;
+                next.rad[0][slot] = sct.rad[k].x; next.rad[1][slot] = sct.rad[k].y; next.rad[2][slot] = sct.rad[k].z;
+                next.pixel[slot] = ps.pixel;
+                next.sample[slot] = ps.sample;
+                next.path[slot] = ps.path * 2u + (uint32_t)k;
+                next.depth_n[slot] = (depth + 1u) << 24;
+            }
         }
     }
     const uint32_t ss = wave_append(&q.counters->surf_count, want_surf);
@@ -596,8 +627,9 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
     if (p == 0) {  // the tallies are per wave already
-        if (n_total) atomicAdd(&counters->total, (unsigned long long)n_total);
-        if (n_left) atomicAdd(&counters->left, (unsigned long long)n_left);
+        Counters::Tally& t = counters->tally[blockIdx.x & (kTallyStripes - 1)];
+        if (n_total) atomicAdd(&t.total, (unsigned long long)n_total);
+        if (n_left) atomicAdd(&t.left, (unsigned long long)n_left);
     }
 }
 
@@ -611,6 +643,8 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_TRACE_W
     Ray r;
     SceneHit h;
     PathState ps;
+    ps.pixel = 0xffffffffu;
+    V3 add = mk(0, 0, 0);
     if (live) {
         r.o = mk(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
         r.d = mk(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
@@ -622,12 +656,13 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_TRACE_W
         V3 em;
         const int what = trace_one<MODE, MESH_ONLY>(sc, r, ps.rad, h, em, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
         if (what == 0) n_left = 1;
-        if (what == 1) film_add(film, ps.pixel, em);
+        if (what == 1) add = em;
         want = what == 2;
     }
     const V3 em2 = shade_lane(sc, pass, q, 1 - in, want, r, ps, h);
-    if (want) film_add(film, ps.pixel, em2);
-    wave_tally(q.counters, live ? 1u : 0u, n_left, 0);
+    if (want) add = em2;
+    film_add_wave(film, ps.pixel, add);
+    wave_tally(q.counters, 0, n_left, 0);  // the rays of this launch themselves are counted by the host
 }
 
 // ComputeDirectLighting's loop body for one (surface point, light) pair
@@ -636,43 +671,43 @@ template <int MODE>
 __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_WAVES : 2) k_direct(DScene sc, Queues q, uint32_t n_surf, double* __restrict__ film) {
     const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = i < n_surf;
-    {
-        const unsigned long long mask = __ballot(live);
-        if (mask != 0 && (int)(threadIdx.x & 63) == __ffsll((long long)mask) - 1) atomicAdd(&q.counters->shadow, (unsigned long long)__popcll(mask));
-    }
-    if (!live) return;
-    const rt_light L = sc.lights[blockIdx.y];
-    const rt_material m = sc.materials[q.surfs.material[i]];
-    const V3 p = mk(q.surfs.p[0][i], q.surfs.p[1][i], q.surfs.p[2][i]);
-    const V3 n = mk(q.surfs.n[0][i], q.surfs.n[1][i], q.surfs.n[2][i]);
-    V3 dir = ld3(L.position) - p;  // PointLight.Sample, light.go:29-35
-    const double dist = length(dir);
-    dir = dir / dist;
-    const V3 wi = m.kind == RT_MAT_LAMBERTIAN ? dir : unit(dir);
-    Ray sh{p + n * kEps, wi};
-    if (scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs})) return;
-    V3 contrib;
-    if (m.kind == RT_MAT_LAMBERTIAN) {
-        const double ndl = go_max(0, dot(n, dir));
-        const V3 alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
-        contrib = (alb * ld3(L.intensity)) * ndl;
-    } else {
-        const V3 wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
-        if (m.kind == RT_MAT_METAL) {
-            const V3 val = mf_evaluate(m.fuzz, ld3(m.albedo), wo, wi, n);
-            const double ct = go_max(0, dot(n, wi));
-            contrib = (ld3(L.intensity) * val) * ct;
+    uint32_t pixel = 0xffffffffu;
+    V3 contrib = mk(0, 0, 0);
+    if (live) {
+        pixel = q.surfs.pixel[i];
+        const rt_light L = sc.lights[blockIdx.y];
+        const rt_material m = sc.materials[q.surfs.material[i]];
+        const V3 p = mk(q.surfs.p[0][i], q.surfs.p[1][i], q.surfs.p[2][i]);
+        const V3 n = mk(q.surfs.n[0][i], q.surfs.n[1][i], q.surfs.n[2][i]);
+        V3 dir = ld3(L.position) - p;  // PointLight.Sample, light.go:29-35
+        const double dist = length(dir);
+        dir = dir / dist;
+        const V3 wi = m.kind == RT_MAT_LAMBERTIAN ? dir : unit(dir);
+        Ray sh{p + n * kEps, wi};
+        if (scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs})) {
+            // in shadow: nothing to add
+        } else if (m.kind == RT_MAT_LAMBERTIAN) {
+            const double ndl = go_max(0, dot(n, dir));
+            const V3 alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
+            contrib = (alb * ld3(L.intensity)) * ndl;
         } else {
-            double eta_i = m.ior_exterior, eta_t = m.ior_interior;
-            if (q.surfs.inside[i]) { const double tmp = eta_i; eta_i = eta_t; eta_t = tmp; }
-            const double cos_i = go_max(0, dot(wi, n));
-            const double fresnel = reflectance(cos_i, eta_i, eta_t);
-            const V3 val = mf_evaluate(m.roughness, mk(1, 1, 1), wo, wi, n) * fresnel;
-            const double ct = go_max(0, dot(n, wi));
-            contrib = (ld3(L.intensity) * val) * ct;
+            const V3 wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
+            if (m.kind == RT_MAT_METAL) {
+                const V3 val = mf_evaluate(m.fuzz, ld3(m.albedo), wo, wi, n);
+                const double ct = go_max(0, dot(n, wi));
+                contrib = (ld3(L.intensity) * val) * ct;
+            } else {
+                double eta_i = m.ior_exterior, eta_t = m.ior_interior;
+                if (q.surfs.inside[i]) { const double tmp = eta_i; eta_i = eta_t; eta_t = tmp; }
+                const double cos_i = go_max(0, dot(wi, n));
+                const double fresnel = reflectance(cos_i, eta_i, eta_t);
+                const V3 val = mf_evaluate(m.roughness, mk(1, 1, 1), wo, wi, n) * fresnel;
+                const double ct = go_max(0, dot(n, wi));
+                contrib = (ld3(L.intensity) * val) * ct;
+            }
         }
     }
-    film_add(film, q.surfs.pixel[i], contrib);
+    film_add_wave(film, pixel, contrib);
 }
 
 // renderPixel's quantisation (render.go:218-224).

@@ -418,6 +418,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     uint64_t traverse_launches = 0, culled_rays = 0;
     Counters host{};
     uint64_t pool_top = 0;
+    uint64_t launched_rays = 0, shadow_rays = 0;  // what the host can count itself is not counted on the device
 
     auto read_counters = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(&host, q.counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
@@ -520,6 +521,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                 if (host.next_count > q.ray_capacity || host.surf_count > q.surf_capacity) return fail(RT_ERR_DEVICE, "internal queue overflow");
                 if (host.surf_count > 0) {
                     launch_direct(sc->dev, q, host.surf_count, o->mode, film, stream);
+                    shadow_rays += (uint64_t)host.surf_count * (uint64_t)sc->dev.n_lights;  // one occlusion ray per surface point and light
                     HIP_TRY(hipGetLastError());
                 }
                 uint32_t n = host.next_count;
@@ -548,6 +550,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                 HIP_TRY(events.next(&ev));
                 HIP_TRY(hipEventRecord(ev->a, stream));
                 launch_trace(sc->dev, pass, q, cur, n, o->mode, sc->mesh_only, film, stream);
+                launched_rays += n;
                 HIP_TRY(hipEventRecord(ev->b, stream));
                 HIP_TRY(hipGetLastError());
                 traverse_launches++;
@@ -584,14 +587,16 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
 #endif
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        stats->total_rays = host.total + culled_rays;  // rays of culled tiles count as traced and as having left the scene
-        stats->rays_exceeded_depth = host.exceeded;
-        stats->rays_left_scene = host.left + culled_rays;
-        stats->shadow_rays = host.shadow;
+        uint64_t total = launched_rays, exceeded = 0, left = 0;
+        for (const Counters::Tally& t : host.tally) { total += t.total; exceeded += t.exceeded; left += t.left; }
+        stats->total_rays = total + culled_rays;  // rays of culled tiles count as traced and as having left the scene
+        stats->rays_exceeded_depth = exceeded;
+        stats->rays_left_scene = left + culled_rays;
+        stats->shadow_rays = shadow_rays;
         stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         stats->traverse_seconds = events.ms * 1e-3;
         stats->traverse_launches = traverse_launches;
-        stats->traverse_rays = host.total + culled_rays;  // every counted ray was settled by exactly one of the timed launches
+        stats->traverse_rays = total + culled_rays;  // every counted ray was settled by exactly one of the timed launches
         stats->culled_rays = culled_rays;
     }
     return RT_OK;

@@ -134,13 +134,18 @@ struct SurfQ {
 };
 constexpr size_t kSurfBytes = 12 * 8 + 4 * 4;
 
-// Every counter sits in a 128-byte line of its own: atomics on different counters then go to different L2 channels
-// instead of queueing behind one another on a single line (thousands of waves append and tally at the same time).
+// An atomic on one address is performed at the memory side (the L2s of the XCDs are not coherent with each other)
+// and only some tens of millions of them finish per second: every wave of a launch adding to the same counter is
+// what bounds the launch.  So the statistics are kept in kTallyStripes copies, each in a 128-byte line of its own
+// (a wave picks one by its workgroup index; the host adds them up), what the host can count itself (rays launched,
+// occlusion rays) is not counted on the device at all, and each cursor has a line of its own.
+constexpr int kTallyStripes = 64;
 struct Counters {
-    alignas(128) unsigned long long total;     // RenderStats (render.go:38-45) ...
-    alignas(128) unsigned long long exceeded;
-    alignas(128) unsigned long long left;
-    alignas(128) unsigned long long shadow;    // ... + occlusion rays
+    struct alignas(128) Tally {
+        unsigned long long total;     // RenderStats (render.go:38-45): rays counted without being launched (children cut or invalid)
+        unsigned long long exceeded;
+        unsigned long long left;
+    } tally[kTallyStripes];
     alignas(128) unsigned int next_count;      // append cursor of the next generation's rays (first of the cursors the host resets)
     alignas(128) unsigned int surf_count;      // append cursor of the lit surface points
     struct alignas(128) Cursor {
