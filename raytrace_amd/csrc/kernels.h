@@ -26,6 +26,7 @@ struct PassDesc {
     // `order` set, queue k hands out order[queue_off[k] + i], i < queue_len[k] (tile numbers, costliest
     // first); without it, its tiles in ascending order.  With `cost` set, every work item adds the clock ticks
     // it took to cost[tile].
+    int32_t max_waves, pad1;        // primary launch: at most this many persistent waves (the queue stripes are sized for them)
     const int32_t* order;
     uint32_t* cost;
     uint32_t queue_off[8], queue_len[8];
@@ -35,16 +36,21 @@ struct Queues {
     RayQ rays[2];   // two generations: a launch traces rays[in] and appends the scattered children to rays[out]
     SurfQ surfs;    // lit surface points of the generation being shaded
     Counters* counters;
-    uint32_t ray_capacity, surf_capacity;
+    uint32_t ray_stripe_cap, surf_stripe_cap;  // entries per stripe; stripe s of a queue is [s * cap, (s + 1) * cap)
+};
+
+// Entries waiting in each stripe of a queue (what the cursors said, less what the host set aside).
+struct StripeCounts {
+    uint32_t n[kQueueStripes];
 };
 
 // cam and q point to DEVICE copies of the structs
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
                     double* film, hipStream_t s);
-// traces rays[in][0 .. n) and appends their children to rays[1 - in]
-void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, uint32_t n, int mode, bool mesh_only, double* film,
+// traces the first n.n[s] rays of every stripe s of rays[in] and appends their children to rays[1 - in]
+void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, const StripeCounts& n, int mode, bool mesh_only, double* film,
                   hipStream_t s);
-void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode, double* film, hipStream_t s);
+void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf, int mode, double* film, hipStream_t s);
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s);
 // src and dst: packed dx*dy RGBA8 device images; tmp: dx*dy*3 float64
 #ifdef RT_VISIT_STATS

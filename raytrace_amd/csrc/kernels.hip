@@ -299,7 +299,7 @@ RT_DEV void wave_tally(Counters* c, uint32_t total, uint32_t left, uint32_t exce
     left = wave_sum(left);
     exceeded = wave_sum(exceeded);
     if ((threadIdx.x & 63) == 0) {
-        Counters::Tally& t = c->tally[blockIdx.x & (kTallyStripes - 1)];
+        Counters::Tally& t = c->tally[(blockIdx.x + blockIdx.y * 5u) & (kTallyStripes - 1)];
         if (total) atomicAdd(&t.total, (unsigned long long)total);
         if (left) atomicAdd(&t.left, (unsigned long long)left);
         if (exceeded) atomicAdd(&t.exceeded, (unsigned long long)exceeded);
@@ -362,8 +362,8 @@ struct PathState {
 // appended to the next generation (ballot compaction, one atomic per wave and queue), the surface point appended
 // for ComputeDirectLighting.  Returns the hit's emission, which the caller adds to the film.  Must be reached by
 // all lanes of the wave.
-RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, int out, bool live, const Ray& r, const PathState& ps,
-                       const SceneHit& h) {
+RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, int out, uint32_t stripe, bool live, const Ray& r,
+                       const PathState& ps, const SceneHit& h) {
     const RayQ& next = q.rays[out];
     V3 emission = mk(0, 0, 0);
     uint32_t n_cut = 0, n_counted = 0;  // children beyond MaxRayDepth or invalid: counted, never traced
@@ -405,14 +405,16 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
         const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
         uint32_t base = 0;
         if (n0 + n1 != 0) {
-            if (lane == 0) base = atomicAdd(&q.counters->next_count, n0 + n1);
+            if (lane == 0) base = atomicAdd(&q.counters->next_cursor[stripe].v, n0 + n1);
             base = __shfl(base, 0, 64);
         }
+        const uint32_t first = stripe * q.ray_stripe_cap;
         const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const uint32_t slot = k == 0 ? base + (uint32_t)__popcll(m0 & below) : base + n0 + (uint32_t)__popcll(m1 & below);
-            if (child_ok[k] && slot < q.ray_capacity) {
+            const uint32_t at_stripe = k == 0 ? base + (uint32_t)__popcll(m0 & below) : base + n0 + (uint32_t)__popcll(m1 & below);
+            const uint32_t slot = first + at_stripe;
+            if (child_ok[k] && at_stripe < q.ray_stripe_cap) {  // the host sizes the launches so that a stripe never fills up, and checks the cursors
                 next.o[0][slot] = at.x; next.o[1][slot] = at.y; next.o[2][slot] = at.z;
                 next.d[0][slot] = sct.dir[k].x; next.d[1][slot] = sct.dir[k].y; next.d[2][slot] = sct.dir[k].z;
                 next.rad[0][slot] = sct.rad[k].x; next.rad[1][slot] = sct.rad[k].y; next.rad[2][slot] = sct.rad[k].z;
@@ -423,8 +425,9 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
             }
         }
     }
-    const uint32_t ss = wave_append(&q.counters->surf_count, want_surf);
-    if (want_surf && ss < q.surf_capacity) {
+    const uint32_t ss_stripe = wave_append(&q.counters->surf_cursor[stripe].v, want_surf);
+    const uint32_t ss = stripe * q.surf_stripe_cap + ss_stripe;
+    if (want_surf && ss_stripe < q.surf_stripe_cap) {
         q.surfs.p[0][ss] = at.x; q.surfs.p[1][ss] = at.y; q.surfs.p[2][ss] = at.z;
         q.surfs.n[0][ss] = s_n.x; q.surfs.n[1][ss] = s_n.y; q.surfs.n[2][ss] = s_n.z;
         q.surfs.wo[0][ss] = s_wo.x; q.surfs.wo[1][ss] = s_wo.y; q.surfs.wo[2][ss] = s_wo.z;
@@ -468,7 +471,7 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // pass, traced by one wave (lane p of it).  See k_primary for how lanes are dealt to samples and pixels.
 template <int MODE, bool MESH_ONLY, bool SHADE>
 RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, double* __restrict__ film, long long v,
-                         uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left) {
+                         uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left, uint32_t& rot) {
     const int lanes_s = 1 << pass.log2_s;       // lanes (= samples in flight) per pixel
     const int px_per_iter = 64 >> pass.log2_s;  // pixels a wave traces at a time
     const int my_px = p >> pass.log2_s, my_s = p & (lanes_s - 1);
@@ -534,7 +537,8 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
             }
             n_left += (uint32_t)__popcll(__ballot(missed));
             if (SHADE) {
-                const V3 em2 = shade_lane(sc, pass, q, 0, want, r, ps, h);
+                // successive rounds of a wave append to successive stripes: over a launch every stripe receives its share
+                const V3 em2 = shade_lane(sc, pass, q, 0, rot++ & (kQueueStripes - 1), want, r, ps, h);
                 if (want) { acc_lds[0] += em2.x; acc_lds[64] += em2.y; acc_lds[128] += em2.z; }
             }
 #ifdef RT_VISIT_STATS
@@ -588,6 +592,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
     const uint32_t n_sub = 64u / (uint32_t)pass.block_px;  // items per tile
     const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
     uint32_t n_total = 0, n_left = 0;
+    uint32_t rot = blockIdx.x;  // stripe of the append queues this wave's next round writes to
     // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
     auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
         const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
@@ -623,7 +628,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         const long long t_start = pass.cost ? clock64() : 0;
         sub = __shfl(sub, 0, 64);
         primary_item<MODE, MESH_ONLY, SHADE>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
-                                             reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left);
+                                             reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left, rot);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
     if (p == 0) {  // the tallies are per wave already
@@ -634,9 +639,12 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
 }
 
 template <int MODE, bool MESH_ONLY>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_TRACE_WAVES : 2) k_trace(DScene sc, PassDesc pass, Queues q, int in, uint32_t n, double* __restrict__ film) {
-    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
-    const bool live = i < n;
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_TRACE_WAVES : 2) k_trace(DScene sc, PassDesc pass, Queues q, int in, StripeCounts cnt, double* __restrict__ film) {
+    // blockIdx.y is the stripe of rays[in] this wave reads; its children go to stripe (x + y) % stripes, so the waves
+    // that share an x write to all different stripes and an output stripe receives at most gridDim.x waves' children
+    const uint32_t at_stripe = blockIdx.x * kTraceBlock + threadIdx.x;
+    const bool live = at_stripe < cnt.n[blockIdx.y];
+    const uint32_t i = blockIdx.y * q.ray_stripe_cap + at_stripe;
     const RayQ& rays = q.rays[in];
     bool want = false;
     uint32_t n_left = 0;
@@ -659,7 +667,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_TRACE_W
         if (what == 1) add = em;
         want = what == 2;
     }
-    const V3 em2 = shade_lane(sc, pass, q, 1 - in, want, r, ps, h);
+    const V3 em2 = shade_lane(sc, pass, q, 1 - in, (blockIdx.x + blockIdx.y) & (kQueueStripes - 1), want, r, ps, h);
     if (want) add = em2;
     film_add_wave(film, ps.pixel, add);
     wave_tally(q.counters, 0, n_left, 0);  // the rays of this launch themselves are counted by the host
@@ -668,14 +676,17 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_TRACE_W
 // ComputeDirectLighting's loop body for one (surface point, light) pair
 // (material_lambertian.go:23-52, material_metal.go:68-106, material_dielectric.go:128-170).
 template <int MODE>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_WAVES : 2) k_direct(DScene sc, Queues q, uint32_t n_surf, double* __restrict__ film) {
-    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
-    const bool live = i < n_surf;
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_WAVES : 2) k_direct(DScene sc, Queues q, StripeCounts cnt, double* __restrict__ film) {
+    // blockIdx.y = light * stripes + stripe of the surface-point queue
+    const uint32_t stripe = blockIdx.y & (kQueueStripes - 1), light = blockIdx.y / kQueueStripes;
+    const uint32_t at_stripe = blockIdx.x * kTraceBlock + threadIdx.x;
+    const bool live = at_stripe < cnt.n[stripe];
+    const uint32_t i = stripe * q.surf_stripe_cap + at_stripe;
     uint32_t pixel = 0xffffffffu;
     V3 contrib = mk(0, 0, 0);
     if (live) {
         pixel = q.surfs.pixel[i];
-        const rt_light L = sc.lights[blockIdx.y];
+        const rt_light L = sc.lights[light];
         const rt_material m = sc.materials[q.surfs.material[i]];
         const V3 p = mk(q.surfs.p[0][i], q.surfs.p[1][i], q.surfs.p[2][i]);
         const V3 n = mk(q.surfs.n[0][i], q.surfs.n[1][i], q.surfs.n[2][i]);
@@ -811,7 +822,9 @@ void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, 
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);
-        const dim3 grid(std::min(resident, (tiles + 7u) & ~7u)), block(kTraceBlock);
+        unsigned waves = std::min(resident, (tiles + 7u) & ~7u);
+        if (pd.max_waves > 0) waves = std::min(waves, (unsigned)pd.max_waves);
+        const dim3 grid(waves), block(kTraceBlock);
         hipLaunchKernelGGL(kernel, grid, block, lds, s, sc, cam, pd, q, film);
     };
     auto pick = [&](auto mode_tag) {
@@ -823,10 +836,16 @@ void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, 
     else pick(std::integral_constant<int, RT_MODE_FAST>{});
 }
 
-void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, uint32_t n, int mode, bool mesh_only, double* film,
+static uint32_t most(const StripeCounts& c) {
+    uint32_t m = 0;
+    for (uint32_t v : c.n) m = std::max(m, v);
+    return m;
+}
+
+void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, const StripeCounts& n, int mode, bool mesh_only, double* film,
                   hipStream_t s) {
-    if (n == 0) return;
-    const dim3 grid(trace_blocks(n)), block(kTraceBlock);
+    if (most(n) == 0) return;
+    const dim3 grid(trace_blocks(most(n)), kQueueStripes), block(kTraceBlock);
     const size_t lds = stack_bytes(sc, mode);
     if (mode == RT_MODE_REFERENCE) {
         if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true>), grid, block, lds, s, sc, pass, q, in, n, film);
@@ -837,9 +856,9 @@ void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int i
     }
 }
 
-void launch_direct(const DScene& sc, const Queues& q, uint32_t n_surf, int mode, double* film, hipStream_t s) {
-    if (n_surf == 0 || sc.n_lights == 0) return;
-    dim3 grid(trace_blocks(n_surf), (unsigned)sc.n_lights);
+void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf, int mode, double* film, hipStream_t s) {
+    if (most(n_surf) == 0 || sc.n_lights == 0) return;
+    dim3 grid(trace_blocks(most(n_surf)), (unsigned)sc.n_lights * kQueueStripes);
     if (mode == RT_MODE_REFERENCE)
         hipLaunchKernelGGL(k_direct<RT_MODE_REFERENCE>, grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, film);
     else

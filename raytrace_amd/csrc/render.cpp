@@ -25,6 +25,8 @@ namespace rt {
 struct WorkBuffers {
     DeviceBuffers mem;
     uint32_t q = 0;  // paths per launch at most
+    uint32_t primary_waves = 0;  // persistent waves of a primary launch at most (the stripes are sized for that many)
+    uint32_t stripe_rays = 0;    // rays of one stripe a trace launch takes at most
     Queues queues{};
     Queues* d_queues = nullptr;   // device copies read by k_primary
     DCamera* d_camera = nullptr;
@@ -112,16 +114,23 @@ int ensure_work(rt_scene* sc) {
     char *rays0 = nullptr, *rays1 = nullptr, *surfs = nullptr;
     // a scene that never shades needs none of the queues (kernels still get valid pointers)
     const size_t qq = sc->all_terminal ? 64 : q;
-    // a launch traces at most q rays and each of them scatters at most two children
-    HIP_TRY(w->mem.alloc(2 * qq * kRayBytes, &rays0));
-    HIP_TRY(w->mem.alloc(2 * qq * kRayBytes, &rays1));
-    HIP_TRY(w->mem.alloc(qq * kSurfBytes, &surfs));
+    // Stripe capacities.  A primary launch traces at most q paths in rounds of a wave that are at least 90 % full, and
+    // wave w sends its r-th round to stripe (w + r) % stripes: a stripe receives at most rounds / stripes + waves rounds
+    // of 64 surface points and 128 children.  A trace launch takes at most stripe_rays rays of each stripe and writes
+    // at most ceil(stripe_rays / 64) waves' children and surface points to each stripe (see k_trace).
+    w->primary_waves = (uint32_t)std::min<size_t>(4096, std::max<size_t>(64, qq / 2048));
+    const size_t rounds = (qq + 63) / 64 * 10 / 9 / kQueueStripes + w->primary_waves + 2;
+    const size_t ray_cap = rounds * 128, surf_cap = rounds * 64;
+    w->stripe_rays = (uint32_t)(rounds * 64 - 64);
+    HIP_TRY(w->mem.alloc(kQueueStripes * ray_cap * kRayBytes, &rays0));
+    HIP_TRY(w->mem.alloc(kQueueStripes * ray_cap * kRayBytes, &rays1));
+    HIP_TRY(w->mem.alloc(kQueueStripes * surf_cap * kSurfBytes, &surfs));
     HIP_TRY(w->mem.alloc(1, &w->queues.counters));
-    carve(w->queues.rays[0], rays0, 2 * qq);
-    carve(w->queues.rays[1], rays1, 2 * qq);
-    carve(w->queues.surfs, surfs, qq);
-    w->queues.ray_capacity = (uint32_t)(2 * qq);
-    w->queues.surf_capacity = (uint32_t)qq;
+    carve(w->queues.rays[0], rays0, kQueueStripes * ray_cap);
+    carve(w->queues.rays[1], rays1, kQueueStripes * ray_cap);
+    carve(w->queues.surfs, surfs, kQueueStripes * surf_cap);
+    w->queues.ray_stripe_cap = (uint32_t)ray_cap;
+    w->queues.surf_stripe_cap = (uint32_t)surf_cap;
     HIP_TRY(w->mem.alloc(1, &w->d_queues));
     HIP_TRY(w->mem.alloc(1, &w->d_camera));
     HIP_TRY(hipMemcpy(w->d_queues, &w->queues, sizeof(Queues), hipMemcpyHostToDevice));
@@ -427,7 +436,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         return RT_OK;
     };
     auto reset_cursors = [&]() -> int {  // zero the append and tile cursors, keep the statistics
-        HIP_TRY(hipMemsetAsync(&q.counters->next_count, 0, sizeof(Counters) - offsetof(Counters, next_count), stream));
+        HIP_TRY(hipMemsetAsync(&q.counters->next_cursor[0], 0, sizeof(Counters) - offsetof(Counters, next_cursor), stream));
         return RT_OK;
     };
 
@@ -489,6 +498,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             }
             pass.tile_begin = t0;
             pass.n_pixels = nt * 64;
+            pass.max_waves = (int32_t)w.primary_waves;
             const bool whole = t0 == 0 && nt == tiles_total;
             pass.order = (want_order && w.order_valid && whole) ? w.tile_order : nullptr;
             pass.cost = (pilot && whole) ? w.tile_cost : nullptr;
@@ -518,38 +528,54 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                     return fail(RT_ERR_CANCELLED, "render cancelled");
                 }
                 if (int rc = read_counters()) return rc;
-                if (host.next_count > q.ray_capacity || host.surf_count > q.surf_capacity) return fail(RT_ERR_DEVICE, "internal queue overflow");
-                if (host.surf_count > 0) {
-                    launch_direct(sc->dev, q, host.surf_count, o->mode, film, stream);
-                    shadow_rays += (uint64_t)host.surf_count * (uint64_t)sc->dev.n_lights;  // one occlusion ray per surface point and light
+                StripeCounts rays_n{}, surf_n{};
+                uint64_t n_surf = 0;
+                for (int k = 0; k < kQueueStripes; k++) {
+                    rays_n.n[k] = host.next_cursor[k].v;
+                    surf_n.n[k] = host.surf_cursor[k].v;
+                    if (rays_n.n[k] > q.ray_stripe_cap || surf_n.n[k] > q.surf_stripe_cap) return fail(RT_ERR_DEVICE, "internal queue overflow");
+                    n_surf += surf_n.n[k];
+                }
+                if (n_surf > 0) {
+                    launch_direct(sc->dev, q, surf_n, o->mode, film, stream);
+                    shadow_rays += n_surf * (uint64_t)sc->dev.n_lights;  // one occlusion ray per surface point and light
                     HIP_TRY(hipGetLastError());
                 }
-                uint32_t n = host.next_count;
-                if (n > w.q) {  // park the excess on the overflow stack; bounded by q * (MaxRayDepth + 1)
-                    const uint64_t excess = n - w.q;
-                    if (!w.pool_base) {
-                        const uint64_t want = (uint64_t)w.q * (uint64_t)(o->max_ray_depth + 1);
-                        hipError_t pe = hipMalloc(&w.pool_base, want * kRayBytes);
-                        if (pe != hipSuccess) { w.pool_base = nullptr; return fail(RT_ERR_NOMEM, hipGetErrorString(pe)); }
-                        carve(w.pool, w.pool_base, want);
-                        w.pool_capacity = want;
+                // This launch takes at most q rays in all and stripe_rays of a stripe; the rest is parked on the overflow
+                // stack (bounded by q * (MaxRayDepth + 1)) and comes back when a generation has died out.
+                uint64_t n = 0;
+                for (int k = 0; k < kQueueStripes; k++) {
+                    const uint32_t keep = (uint32_t)std::min<uint64_t>(std::min(rays_n.n[k], w.stripe_rays), (uint64_t)w.q - n);
+                    const uint64_t excess = rays_n.n[k] - keep;
+                    if (excess) {
+                        if (!w.pool_base) {
+                            const uint64_t want = (uint64_t)w.q * (uint64_t)(o->max_ray_depth + 1);
+                            hipError_t pe = hipMalloc(&w.pool_base, want * kRayBytes);
+                            if (pe != hipSuccess) { w.pool_base = nullptr; return fail(RT_ERR_NOMEM, hipGetErrorString(pe)); }
+                            carve(w.pool, w.pool_base, want);
+                            w.pool_capacity = want;
+                        }
+                        if (pool_top + excess > w.pool_capacity) return fail(RT_ERR_NOMEM, "ray pool exhausted");
+                        HIP_TRY(copy_rays(w.pool, pool_top, q.rays[cur], (uint64_t)k * q.ray_stripe_cap + keep, excess, stream));
+                        pool_top += excess;
                     }
-                    if (pool_top + excess > w.pool_capacity) return fail(RT_ERR_NOMEM, "ray pool exhausted");
-                    HIP_TRY(copy_rays(w.pool, pool_top, q.rays[cur], w.q, excess, stream));
-                    pool_top += excess;
-                    n = w.q;
+                    rays_n.n[k] = keep;
+                    n += keep;
                 }
                 if (n == 0) {
                     if (pool_top == 0) break;
-                    const uint64_t take = std::min<uint64_t>(pool_top, w.q);
-                    HIP_TRY(copy_rays(q.rays[cur], 0, w.pool, pool_top - take, take, stream));
-                    pool_top -= take;
-                    n = (uint32_t)take;
+                    for (int k = 0; k < kQueueStripes && pool_top > 0 && n < w.q; k++) {  // deal the parked rays to the stripes
+                        const uint64_t take = std::min<uint64_t>(std::min<uint64_t>(pool_top, w.stripe_rays), (uint64_t)w.q - n);
+                        HIP_TRY(copy_rays(q.rays[cur], (uint64_t)k * q.ray_stripe_cap, w.pool, pool_top - take, take, stream));
+                        pool_top -= take;
+                        rays_n.n[k] = (uint32_t)take;
+                        n += take;
+                    }
                 }
                 if (int rc = reset_cursors()) return rc;
                 HIP_TRY(events.next(&ev));
                 HIP_TRY(hipEventRecord(ev->a, stream));
-                launch_trace(sc->dev, pass, q, cur, n, o->mode, sc->mesh_only, film, stream);
+                launch_trace(sc->dev, pass, q, cur, rays_n, o->mode, sc->mesh_only, film, stream);
                 launched_rays += n;
                 HIP_TRY(hipEventRecord(ev->b, stream));
                 HIP_TRY(hipGetLastError());

@@ -140,17 +140,22 @@ constexpr size_t kSurfBytes = 12 * 8 + 4 * 4;
 // (a wave picks one by its workgroup index; the host adds them up), what the host can count itself (rays launched,
 // occlusion rays) is not counted on the device at all, and each cursor has a line of its own.
 constexpr int kTallyStripes = 64;
+// The append queues are cut into kQueueStripes regions of equal capacity with a cursor each, for the same reason: a
+// wave reserves its slots in one stripe (chosen so that the stripes fill evenly), the host reads all cursors and the
+// next launch walks every stripe.
+constexpr int kQueueStripes = 32;
 struct Counters {
     struct alignas(128) Tally {
         unsigned long long total;     // RenderStats (render.go:38-45): rays counted without being launched (children cut or invalid)
         unsigned long long exceeded;
         unsigned long long left;
     } tally[kTallyStripes];
-    alignas(128) unsigned int next_count;      // append cursor of the next generation's rays (first of the cursors the host resets)
-    alignas(128) unsigned int surf_count;      // append cursor of the lit surface points
     struct alignas(128) Cursor {
         unsigned int v;
-    } tile_cursor[8];                          // next tile of each XCD's share of a primary launch
+    };
+    Cursor next_cursor[kQueueStripes];         // append cursors of the next generation's rays, one per stripe (first of the cursors the host resets)
+    Cursor surf_cursor[kQueueStripes];         // append cursors of the lit surface points
+    Cursor tile_cursor[8];                     // next tile of each XCD's share of a primary launch
 };
 
 }  // namespace rt

@@ -355,3 +355,20 @@ def test_tiles_outside_the_screen_bounds_are_settled_without_tracing(camera, mon
             assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
             assert torch.equal(a == 0, b == 0)
             assert a.any()
+
+
+@pytest.mark.parametrize("name", ["material", "cornell"])
+def test_small_queues_park_rays_and_give_the_same_image(name, monkeypatch):
+    """Queues of 4096 paths: many launches per pass, stripes of a few hundred entries, and generations that outgrow
+    a launch (two children per dielectric hit) parked on the overflow stack.  Same samples, so the same counters and
+    the same image up to the order of the float sums."""
+    sc = {"material": lambda: scenes.material(dx=96, dy=96, spp=8, tex_size=(40, 36)),
+          "cornell": lambda: scenes.cornell(dx=80, dy=72, spp=6)}[name]()
+    big = phys.Render(sc)
+    monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
+    small = phys.Render(sc)
+    for k in ("TotalRays", "RaysLeftScene", "RaysExceededDepth", "ShadowRays"):
+        assert getattr(big.Stats, k) == getattr(small.Stats, k), k
+    assert small.Stats.TraverseLaunches > 2 * big.Stats.TraverseLaunches
+    diff = np.abs(big.Image.astype(int) - small.Image.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
