@@ -498,7 +498,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             }
             pass.tile_begin = t0;
             pass.n_pixels = nt * 64;
-            pass.max_waves = (int32_t)w.primary_waves;
+            pass.max_waves = sc->all_terminal ? 0 : (int32_t)w.primary_waves;  // nothing is queued when every material only emits
             const bool whole = t0 == 0 && nt == tiles_total;
             pass.order = (want_order && w.order_valid && whole) ? w.tile_order : nullptr;
             pass.cost = (pilot && whole) ? w.tile_cost : nullptr;
