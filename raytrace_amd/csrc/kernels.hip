@@ -41,7 +41,10 @@ extern __shared__ int32_t dyn_lds[];
 #define RT_PACKET_SHADE_WAVES 4  // ... and when that kernel also runs Material.Resolve
 #endif
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 3  // k_trace
+#define RT_TRACE_WAVES 3  // k_trace, mesh-only scenes
+#endif
+#ifndef RT_TRACE_SHAPES_WAVES
+#define RT_TRACE_SHAPES_WAVES 2  // k_trace for scenes without any mesh: 256 VGPRs, nothing spilled (at 3 waves 168 VGPRs + 328 B of scratch per lane: a third slower on the sphere scenes; with a mesh in the scene the walk's latency wants the third wave)
 #endif
 #ifndef RT_DIRECT_WAVES
 #define RT_DIRECT_WAVES 3  // k_direct
@@ -638,8 +641,8 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
     }
 }
 
-template <int MODE, bool MESH_ONLY>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_TRACE_WAVES : 2) k_trace(DScene sc, PassDesc pass, Queues q, int in, StripeCounts cnt, double* __restrict__ film) {
+template <int MODE, bool MESH_ONLY, int WAVES>
+__global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDesc pass, Queues q, int in, StripeCounts cnt, double* __restrict__ film) {
     // blockIdx.y is the stripe of rays[in] this wave reads; its children go to stripe (x + y) % stripes, so the waves
     // that share an x write to all different stripes and an output stripe receives at most gridDim.x waves' children
     const uint32_t at_stripe = blockIdx.x * kTraceBlock + threadIdx.x;
@@ -848,11 +851,12 @@ void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int i
     const dim3 grid(trace_blocks(most(n)), kQueueStripes), block(kTraceBlock);
     const size_t lds = stack_bytes(sc, mode);
     if (mode == RT_MODE_REFERENCE) {
-        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true>), grid, block, lds, s, sc, pass, q, in, n, film);
-        else hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, false>), grid, block, lds, s, sc, pass, q, in, n, film);
+        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true, 2>), grid, block, lds, s, sc, pass, q, in, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, false, 2>), grid, block, lds, s, sc, pass, q, in, n, film);
     } else {
-        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, true>), grid, block, lds, s, sc, pass, q, in, n, film);
-        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false>), grid, block, lds, s, sc, pass, q, in, n, film);
+        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, true, RT_TRACE_WAVES>), grid, block, lds, s, sc, pass, q, in, n, film);
+        else if (sc.n_meshes > 0) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false, RT_TRACE_WAVES>), grid, block, lds, s, sc, pass, q, in, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false, RT_TRACE_SHAPES_WAVES>), grid, block, lds, s, sc, pass, q, in, n, film);
     }
 }
 

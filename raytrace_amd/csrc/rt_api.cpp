@@ -426,7 +426,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     dev.n_nodes = (int32_t)d->n_nodes;
     dev.n_lights = (int32_t)d->n_lights;
     dev.stack_pairs = stack_pairs;
-    dev.pad = 0;
+    dev.n_meshes = (int32_t)d->n_meshes;
     *out = sc.release();
     return RT_OK;
 }

@@ -91,7 +91,7 @@ struct DScene {
     const double* node_box;  // per node: padded world-space bounds (min xyz, max xyz); fast mode skips a node the ray misses
     int32_t n_nodes, n_lights;
     int32_t stack_pairs;  // depth of the deepest fast tree + 1: capacity of the LDS traversal stack
-    int32_t pad;
+    int32_t n_meshes;     // meshes in the scene (0: no tree walk anywhere, launches favour registers over occupancy)
 };
 
 struct DCamera {
