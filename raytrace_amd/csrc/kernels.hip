@@ -73,8 +73,10 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
 // normal come back through the forward transforms.
 // PACKET (fast mode): the lanes of the wave trace neighbouring rays and walk a mesh together (mesh_collide_packet).
 template <int MODE, bool PACKET = false>
+// uv_now = false: the texture coordinates of an untransformed sphere (atan2 / acos, some hundred instructions) are left
+// at 0; the caller computes them with sphere_uv() from the normal if the hit wins and its material reads them.
 RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in, double tmin, double tmax, Col& c, int& prim,
-                          VisitCounts& cnt, LdsStack ls) {
+                          VisitCounts& cnt, LdsStack ls, bool uv_now = true) {
     Ray r = r_in;
     int chain[4];
     int nchain = 0;
@@ -91,7 +93,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
     switch (kind) {
         case RT_SHAPE_SPHERE:
             hit = sphere_collide(sc.spheres[index], r, tmin, tmax, c);
-            if (hit) sphere_uv(sc.spheres[index], c);
+            if (hit && (uv_now || nchain > 0)) sphere_uv(sc.spheres[index], c);  // a transformed sphere: from the normal in its own frame
             break;
         case RT_SHAPE_QUAD: hit = quad_collide(sc.quads[index], r, tmin, tmax, c); break;
         case RT_SHAPE_CYLINDER: hit = cylinder_collide(sc.cylinders[index], r, tmin, tmax, c); break;
@@ -156,11 +158,19 @@ RT_DEV bool node_box_reachable(const double* b, const Ray& r, V3 inv, double tmi
     return tn <= tf;
 }
 
+RT_DEV bool material_reads_uv(const DScene& sc, int material) {
+    const rt_material& m = sc.materials[material];
+    if (m.kind == RT_MAT_DEBUG_UV) return true;
+    if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_EMITTER) return sc.textures[m.texture].kind != RT_TEX_UNIFORM;
+    return false;  // Metal, Dielectric, DebugNormal never call Texture.At
+}
+
 // The node loop of tracePath (render.go:155-169).  MESH_ONLY: the host has checked that every
 // node is a plain mesh, so the other shapes' code (and its registers) is left out.
 // PACKET (fast mode): the lanes of the wave trace neighbouring rays and walk each mesh together.
+// all_uv: texture coordinates also for hits whose material never reads them (validation entry point).
 template <int MODE, bool MESH_ONLY = false, bool PACKET = false>
-RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, LdsStack ls) {
+RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, LdsStack ls, bool all_uv = false) {
     double min_dist = tmax;
     bool hit = false;
     const bool cull = MODE == RT_MODE_FAST && !MESH_ONLY;  // a mesh clips the ray against its own root box
@@ -190,7 +200,7 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
         if (cull && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
         Col c;
         int prim;
-        const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, ls);
+        const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, ls, false);
         if (got && c.t < min_dist) {
             min_dist = c.t;
             h.c = c;
@@ -198,6 +208,10 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
             h.prim = prim;
             hit = true;
         }
+    }
+    if (!MESH_ONLY && hit) {  // the texture coordinates of the sphere that won, when something will read them
+        const DNode nd = sc.nodes[h.node];
+        if (nd.kind == RT_SHAPE_SPHERE && (all_uv || material_reads_uv(sc, nd.material))) sphere_uv(sc.spheres[nd.index], h.c);
     }
     return hit;
 }
@@ -223,7 +237,7 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
         }
         Col c;
         int prim;
-        if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, cnt, ls)) return true;
+        if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, cnt, ls, false)) return true;
     }
     return false;
 }
@@ -754,7 +768,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_intersect_batch(DScene sc, cons
     h.t = 0;
     for (int k = 0; k < 3; k++) { h.at[k] = 0; h.normal[k] = 0; }
     h.uv[0] = h.uv[1] = 0;
-    if (scene_closest<MODE>(sc, r, tmin, tmax, sh, cnt, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs})) {
+    if (scene_closest<MODE>(sc, r, tmin, tmax, sh, cnt, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, true)) {
         h.node = sh.node;
         h.prim = sh.prim;
         h.t = sh.c.t;
