@@ -474,7 +474,18 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             pilot = true;  // a short pass over the whole frame that records what every tile costs
             s_count = std::min(s_count, kPilotSamples);
         }
-        const int64_t tiles_per_launch = std::max<int64_t>(1, paths_per_launch / (64 * (int64_t)s_count));
+        // lanes per pixel: the widest power of two that keeps >= 90 % of the lanes busy over the rounds
+        int log2_s = 0;
+        for (int l = 6; l > 0; l--) {
+            const int lanes = 1 << l, rounds = (s_count + lanes - 1) / lanes;
+            if (s_count * 10 >= rounds * lanes * 9) { log2_s = l; break; }
+        }
+        if (lanes_override >= 0) log2_s = std::min(lanes_override, 6);
+        // a tile takes 2^log2_s * ceil(s_count / 2^log2_s) rounds of a wave; the queue stripes are sized for launches
+        // of at most q / 64 * 10 / 9 rounds (ensure_work), whatever the lanes are
+        const int64_t rounds_per_tile = ((int64_t)1 << log2_s) * ((s_count + (1 << log2_s) - 1) >> log2_s);
+        int64_t tiles_per_launch = std::max<int64_t>(1, paths_per_launch / (64 * (int64_t)s_count));
+        if (!sc->all_terminal) tiles_per_launch = std::max<int64_t>(1, std::min(tiles_per_launch, ((int64_t)w.q + 63) / 64 * 10 / 9 / rounds_per_tile));
         for (int64_t t0 = 0; t0 < tiles_total; t0 += tiles_per_launch) {
             if (sc->cancel.load()) {
                 (void)hipStreamSynchronize(stream);
@@ -483,13 +494,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             const int64_t nt = std::min(tiles_per_launch, tiles_total - t0);
             pass.sample_begin = s0;
             pass.sample_count = s_count;
-            {   // lanes per pixel: the widest power of two that keeps >= 90 % of the lanes busy over the rounds
-                int log2_s = 0;
-                for (int l = 6; l > 0; l--) {
-                    const int lanes = 1 << l, rounds = (s_count + lanes - 1) / lanes;
-                    if (s_count * 10 >= rounds * lanes * 9) { log2_s = l; break; }
-                }
-                if (lanes_override >= 0) log2_s = std::min(lanes_override, 6);
+            {
                 pass.log2_s = log2_s;
                 // pixels per item: about 1024 rays, at least what the wave traces at a time, at most the tile
                 int block = 64 >> log2_s;
