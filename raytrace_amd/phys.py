@@ -5,7 +5,7 @@ The names, fields and validation errors follow package phys of the reference
 light.go, render.go) so that scenes and tests read like the reference's own.
 Nothing here computes pixels: `Render` flattens the scene into the C structures
 of include/rt_hip.h and calls librt_hip.so, exactly what the Go `phys.Render`
-would do through cgo (see INTEGRATION.md).
+would do through cgo.
 """
 from __future__ import annotations
 
