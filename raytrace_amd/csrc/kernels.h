@@ -43,12 +43,15 @@ struct Queues {
 struct StripeCounts {
     uint32_t n[kQueueStripes];
 };
+struct RayStripeCounts {
+    uint32_t n[kRayStripes];  // the upper half stays 0 unless the scene queues two classes of rays
+};
 
 // cam and q point to DEVICE copies of the structs
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
                     double* film, hipStream_t s);
 // traces the first n.n[s] rays of every stripe s of rays[in] and appends their children to rays[1 - in]
-void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, const StripeCounts& n, int mode, bool mesh_only, double* film,
+void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, const RayStripeCounts& n, int mode, bool mesh_only, double* film,
                   hipStream_t s);
 void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf, int mode, double* film, hipStream_t s);
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s);

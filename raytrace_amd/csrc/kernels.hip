@@ -416,22 +416,35 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
         }
     }
     wave_tally(q.counters, n_counted, 0, n_cut);
-    {   // both children of every lane in one reservation: first children first, in lane order, then the second ones
-        const unsigned long long m0 = __ballot(child_ok[0]), m1 = __ballot(child_ok[1]);
+    // class of a child: 1 when it can reach a mesh (scenes that mix meshes with other shapes, see DScene::walk_box)
+    int cls[2] = {0, 0};
+    if (sc.walk_classes) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (!child_ok[k]) continue;
+            const Ray cr{at, sct.dir[k]};
+            const V3 inv = mk(1.0 / cr.d.x, 1.0 / cr.d.y, 1.0 / cr.d.z);
+            cls[k] = node_box_reachable(sc.walk_box, cr, inv, kEps, kMaxFloat) ? 1 : 0;
+        }
+    }
+    for (int c = 0; c <= sc.walk_classes; c++) {
+        // both children of every lane in one reservation per class: first children first, in lane order, then the second ones
+        const unsigned long long m0 = __ballot(child_ok[0] && cls[0] == c), m1 = __ballot(child_ok[1] && cls[1] == c);
         const int lane = threadIdx.x & 63;
         const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
+        const uint32_t out_stripe = (uint32_t)c * kQueueStripes + stripe;
         uint32_t base = 0;
         if (n0 + n1 != 0) {
-            if (lane == 0) base = atomicAdd(&q.counters->next_cursor[stripe].v, n0 + n1);
+            if (lane == 0) base = atomicAdd(&q.counters->next_cursor[out_stripe].v, n0 + n1);
             base = __shfl(base, 0, 64);
         }
-        const uint32_t first = stripe * q.ray_stripe_cap;
+        const uint32_t first = out_stripe * q.ray_stripe_cap;
         const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const uint32_t at_stripe = k == 0 ? base + (uint32_t)__popcll(m0 & below) : base + n0 + (uint32_t)__popcll(m1 & below);
             const uint32_t slot = first + at_stripe;
-            if (child_ok[k] && at_stripe < q.ray_stripe_cap) {  // the host sizes the launches so that a stripe never fills up, and checks the cursors
+            if (child_ok[k] && cls[k] == c && at_stripe < q.ray_stripe_cap) {  // the host sizes the launches so that a stripe never fills up, and checks the cursors
                 next.o[0][slot] = at.x; next.o[1][slot] = at.y; next.o[2][slot] = at.z;
                 next.d[0][slot] = sct.dir[k].x; next.d[1][slot] = sct.dir[k].y; next.d[2][slot] = sct.dir[k].z;
                 next.rad[0][slot] = sct.rad[k].x; next.rad[1][slot] = sct.rad[k].y; next.rad[2][slot] = sct.rad[k].z;
@@ -656,9 +669,9 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
 }
 
 template <int MODE, bool MESH_ONLY, int WAVES>
-__global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDesc pass, Queues q, int in, StripeCounts cnt, double* __restrict__ film) {
-    // blockIdx.y is the stripe of rays[in] this wave reads; its children go to stripe (x + y) % stripes, so the waves
-    // that share an x write to all different stripes and an output stripe receives at most gridDim.x waves' children
+__global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDesc pass, Queues q, int in, RayStripeCounts cnt, double* __restrict__ film) {
+    // blockIdx.y is the stripe of rays[in] this wave reads; its children go to stripe (x + y) % 32 of their class, so
+    // of the waves that share an x at most gridDim.y / 32 write to the same stripe
     const uint32_t at_stripe = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = at_stripe < cnt.n[blockIdx.y];
     const uint32_t i = blockIdx.y * q.ray_stripe_cap + at_stripe;
@@ -859,10 +872,12 @@ static uint32_t most(const StripeCounts& c) {
     return m;
 }
 
-void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, const StripeCounts& n, int mode, bool mesh_only, double* film,
+void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, const RayStripeCounts& n, int mode, bool mesh_only, double* film,
                   hipStream_t s) {
-    if (most(n) == 0) return;
-    const dim3 grid(trace_blocks(most(n)), kQueueStripes), block(kTraceBlock);
+    uint32_t most_n = 0;
+    for (uint32_t v : n.n) most_n = std::max(most_n, v);
+    if (most_n == 0) return;
+    const dim3 grid(trace_blocks(most_n), sc.walk_classes ? kRayStripes : kQueueStripes), block(kTraceBlock);
     const size_t lds = stack_bytes(sc, mode);
     if (mode == RT_MODE_REFERENCE) {
         if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true, 2>), grid, block, lds, s, sc, pass, q, in, n, film);

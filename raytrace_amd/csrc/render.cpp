@@ -27,6 +27,7 @@ struct WorkBuffers {
     uint32_t q = 0;  // paths per launch at most
     uint32_t primary_waves = 0;  // persistent waves of a primary launch at most (the stripes are sized for that many)
     uint32_t stripe_rays = 0;    // rays of one stripe a trace launch takes at most
+    int ray_stripes = kQueueStripes;  // stripes of a ray queue: twice as many when the scene queues two classes of rays
     Queues queues{};
     Queues* d_queues = nullptr;   // device copies read by k_primary
     DCamera* d_camera = nullptr;
@@ -121,13 +122,16 @@ int ensure_work(rt_scene* sc) {
     w->primary_waves = (uint32_t)std::min<size_t>(4096, std::max<size_t>(64, qq / 2048));
     const size_t rounds = (qq + 63) / 64 * 10 / 9 / kQueueStripes + w->primary_waves + 2;
     const size_t ray_cap = rounds * 128, surf_cap = rounds * 64;
-    w->stripe_rays = (uint32_t)(rounds * 64 - 64);
-    HIP_TRY(w->mem.alloc(kQueueStripes * ray_cap * kRayBytes, &rays0));
-    HIP_TRY(w->mem.alloc(kQueueStripes * ray_cap * kRayBytes, &rays1));
+    // with two classes of rays (DScene::walk_classes) a class has stripes of its own, and of the trace waves that share a
+    // grid x two write to the same stripe: a launch then takes half as many rays of a stripe
+    w->ray_stripes = sc->dev.walk_classes ? kRayStripes : kQueueStripes;
+    w->stripe_rays = (uint32_t)((sc->dev.walk_classes ? rounds / 2 : rounds) * 64 - 64);
+    HIP_TRY(w->mem.alloc((size_t)w->ray_stripes * ray_cap * kRayBytes, &rays0));
+    HIP_TRY(w->mem.alloc((size_t)w->ray_stripes * ray_cap * kRayBytes, &rays1));
     HIP_TRY(w->mem.alloc(kQueueStripes * surf_cap * kSurfBytes, &surfs));
     HIP_TRY(w->mem.alloc(1, &w->queues.counters));
-    carve(w->queues.rays[0], rays0, kQueueStripes * ray_cap);
-    carve(w->queues.rays[1], rays1, kQueueStripes * ray_cap);
+    carve(w->queues.rays[0], rays0, (size_t)w->ray_stripes * ray_cap);
+    carve(w->queues.rays[1], rays1, (size_t)w->ray_stripes * ray_cap);
     carve(w->queues.surfs, surfs, kQueueStripes * surf_cap);
     w->queues.ray_stripe_cap = (uint32_t)ray_cap;
     w->queues.surf_stripe_cap = (uint32_t)surf_cap;
@@ -533,12 +537,16 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                     return fail(RT_ERR_CANCELLED, "render cancelled");
                 }
                 if (int rc = read_counters()) return rc;
-                StripeCounts rays_n{}, surf_n{};
+                RayStripeCounts rays_n{};
+                StripeCounts surf_n{};
                 uint64_t n_surf = 0;
-                for (int k = 0; k < kQueueStripes; k++) {
+                for (int k = 0; k < w.ray_stripes; k++) {
                     rays_n.n[k] = host.next_cursor[k].v;
+                    if (rays_n.n[k] > q.ray_stripe_cap) return fail(RT_ERR_DEVICE, "internal queue overflow");
+                }
+                for (int k = 0; k < kQueueStripes; k++) {
                     surf_n.n[k] = host.surf_cursor[k].v;
-                    if (rays_n.n[k] > q.ray_stripe_cap || surf_n.n[k] > q.surf_stripe_cap) return fail(RT_ERR_DEVICE, "internal queue overflow");
+                    if (surf_n.n[k] > q.surf_stripe_cap) return fail(RT_ERR_DEVICE, "internal queue overflow");
                     n_surf += surf_n.n[k];
                 }
                 if (n_surf > 0) {
@@ -549,7 +557,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                 // This launch takes at most q rays in all and stripe_rays of a stripe; the rest is parked on the overflow
                 // stack (bounded by q * (MaxRayDepth + 1)) and comes back when a generation has died out.
                 uint64_t n = 0;
-                for (int k = 0; k < kQueueStripes; k++) {
+                for (int k = 0; k < w.ray_stripes; k++) {
                     const uint32_t keep = (uint32_t)std::min<uint64_t>(std::min(rays_n.n[k], w.stripe_rays), (uint64_t)w.q - n);
                     const uint64_t excess = rays_n.n[k] - keep;
                     if (excess) {
@@ -569,7 +577,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                 }
                 if (n == 0) {
                     if (pool_top == 0) break;
-                    for (int k = 0; k < kQueueStripes && pool_top > 0 && n < w.q; k++) {  // deal the parked rays to the stripes
+                    for (int k = 0; k < w.ray_stripes && pool_top > 0 && n < w.q; k++) {  // deal the parked rays to the stripes (their class is not kept: it only packs the waves)
                         const uint64_t take = std::min<uint64_t>(std::min<uint64_t>(pool_top, w.stripe_rays), (uint64_t)w.q - n);
                         HIP_TRY(copy_rays(q.rays[cur], (uint64_t)k * q.ray_stripe_cap, w.pool, pool_top - take, take, stream));
                         pool_top -= take;

@@ -427,6 +427,21 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     dev.n_lights = (int32_t)d->n_lights;
     dev.stack_pairs = stack_pairs;
     dev.n_meshes = (int32_t)d->n_meshes;
+    {   // bounds of every node that holds a mesh (directly or under transforms): rays that miss them never walk a tree
+        bool any = false;
+        double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (uint64_t i = 0; i < d->n_nodes; i++) {
+            if (nodes[i].kind != RT_SHAPE_MESH && nodes[i].kind != RT_SHAPE_TRANSFORMED) continue;
+            for (int k = 0; k < 3; k++) {
+                lo[k] = any ? std::min(lo[k], node_box[i * 6 + k]) : node_box[i * 6 + k];
+                hi[k] = any ? std::max(hi[k], node_box[i * 6 + 3 + k]) : node_box[i * 6 + 3 + k];
+            }
+            any = true;
+        }
+        for (int k = 0; k < 3; k++) { dev.walk_box[k] = lo[k]; dev.walk_box[3 + k] = hi[k]; }
+        dev.walk_classes = (any && d->n_meshes > 0 && !sc->mesh_only && std::getenv("RT_NO_RAY_CLASSES") == nullptr) ? 1 : 0;
+        dev.pad = 0;
+    }
     *out = sc.release();
     return RT_OK;
 }

@@ -92,6 +92,12 @@ struct DScene {
     int32_t n_nodes, n_lights;
     int32_t stack_pairs;  // depth of the deepest fast tree + 1: capacity of the LDS traversal stack
     int32_t n_meshes;     // meshes in the scene (0: no tree walk anywhere, launches favour registers over occupancy)
+    // Scenes that mix meshes with other shapes queue scattered rays in two classes: those that can reach a mesh (they
+    // pass through walk_box, the bounds of all mesh nodes) and the others, so that the waves of the next launch hold
+    // either rays that walk a tree or rays that do not, instead of a few walkers per wave.
+    double walk_box[6];
+    int32_t walk_classes;  // 1: the ray queues have kRayStripes stripes, the upper half for the rays that reach walk_box
+    int32_t pad;
 };
 
 struct DCamera {
@@ -144,6 +150,7 @@ constexpr int kTallyStripes = 64;
 // wave reserves its slots in one stripe (chosen so that the stripes fill evenly), the host reads all cursors and the
 // next launch walks every stripe.
 constexpr int kQueueStripes = 32;
+constexpr int kRayStripes = 2 * kQueueStripes;  // ray queues of scenes with two classes of rays (DScene::walk_classes)
 struct Counters {
     struct alignas(128) Tally {
         unsigned long long total;     // RenderStats (render.go:38-45): rays counted without being launched (children cut or invalid)
@@ -153,7 +160,7 @@ struct Counters {
     struct alignas(128) Cursor {
         unsigned int v;
     };
-    Cursor next_cursor[kQueueStripes];         // append cursors of the next generation's rays, one per stripe (first of the cursors the host resets)
+    Cursor next_cursor[kRayStripes];           // append cursors of the next generation's rays, one per stripe (first of the cursors the host resets)
     Cursor surf_cursor[kQueueStripes];         // append cursors of the lit surface points
     Cursor tile_cursor[8];                     // next tile of each XCD's share of a primary launch
 };

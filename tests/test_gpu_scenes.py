@@ -357,13 +357,15 @@ def test_tiles_outside_the_screen_bounds_are_settled_without_tracing(camera, mon
             assert a.any()
 
 
-@pytest.mark.parametrize("name", ["material", "cornell"])
+@pytest.mark.parametrize("name", ["material", "cornell", "teapot"])
 def test_small_queues_park_rays_and_give_the_same_image(name, monkeypatch):
     """Queues of 4096 paths: many launches per pass, stripes of a few hundred entries, and generations that outgrow
     a launch (two children per dielectric hit) parked on the overflow stack.  Same samples, so the same counters and
     the same image up to the order of the float sums."""
     sc = {"material": lambda: scenes.material(dx=96, dy=96, spp=8, tex_size=(40, 36)),
-          "cornell": lambda: scenes.cornell(dx=80, dy=72, spp=6)}[name]()
+          "cornell": lambda: scenes.cornell(dx=80, dy=72, spp=6),
+          # a mesh among other shapes: scattered rays are queued in two classes (those that can reach the mesh, the others)
+          "teapot": lambda: scenes.teapot(dx=96, dy=64, spp=6)}[name]()
     big = phys.Render(sc)
     monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
     small = phys.Render(sc)
