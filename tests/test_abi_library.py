@@ -75,3 +75,21 @@ def test_product_path_fails_loudly_without_a_gpu():
     from raytrace_amd import phys, scenes
     with pytest.raises(Exception):
         phys.Render(scenes.scan(level=1, dx=16, dy=16, spp=1, tex_size=8))
+
+
+def test_bvh_node_record_matches_the_header():
+    """rt_bvh_build's node record is read through a numpy dtype: same size and field offsets as the C struct."""
+    import subprocess, tempfile
+    import numpy as np
+    from raytrace_amd import abi
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "rt_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(rt_bvh_node), '
+           'offsetof(rt_bvh_node, bounds_min), offsetof(rt_bvh_node, bounds_max), offsetof(rt_bvh_node, right), '
+           'offsetof(rt_bvh_node, first), offsetof(rt_bvh_node, count));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        cfile, exe = os.path.join(d, "s.c"), os.path.join(d, "s")
+        open(cfile, "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe])
+        want = [int(x) for x in subprocess.check_output([exe]).split()]
+    dt = np.dtype(abi.BVH_NODE_DTYPE)
+    got = [dt.itemsize] + [dt.fields[k][1] for k in ("bounds_min", "bounds_max", "right", "first", "count")]
+    assert got == want
