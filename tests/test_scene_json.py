@@ -235,3 +235,21 @@ def test_a_scene_read_from_json_renders_the_same_image(name):
     assert np.array_equal(a.Image, b.Image)
     assert (a.Stats.TotalRays, a.Stats.RaysLeftScene, a.Stats.RaysExceededDepth) == \
            (b.Stats.TotalRays, b.Stats.RaysLeftScene, b.Stats.RaysExceededDepth)
+
+
+def test_bvh_build_reports_the_size_it_needs():
+    """rt_bvh_build with too small a node array writes nothing and says how many nodes the tree has."""
+    import ctypes as C
+    from raytrace_amd import _lib
+    lib = _lib.host_library()
+    faces = np.ascontiguousarray(scenes.random_faces(40, seed=5))
+    leaf = np.full(40, -7, dtype=np.int32)
+    nodes = np.zeros(1, dtype=abi.BVH_NODE_DTYPE)
+    count = C.c_uint64(0)
+    assert lib.rt_bvh_build(faces.ctypes.data, 40, nodes.ctypes.data, 1, leaf.ctypes.data, C.byref(count)) != abi.RT_OK
+    assert count.value > 1 and (leaf == -7).all()
+    tree, order = J.mesh_bvh(faces)
+    assert len(tree) == count.value and sorted(order.tolist()) == list(range(40))
+    inner = tree[tree["right"] >= 0]
+    assert (inner["count"] == 0).all() and (tree[tree["right"] < 0]["count"] > 0).all()
+    assert lib.rt_bvh_build(faces.ctypes.data, 0, nodes.ctypes.data, 1, leaf.ctypes.data, C.byref(count)) != abi.RT_OK
