@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Renders a scene in the reference's JSON format (Scene.MarshalJSON, phys/scene.go:82-114; also the body of the
+playground's POST /raytrace/render) on the GPU and writes a PNG, as the playground does with its render
+(playground/main.go:66-110).  usage: render_json.py scene.json out.png [--strict] [--assets DIR] [--reference]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from raytrace_amd import abi, obj, phys
+
+ap = argparse.ArgumentParser()
+ap.add_argument("scene")
+ap.add_argument("out")
+ap.add_argument("--strict", action="store_true", help="read like the reference's own UnmarshalJSON (its type registry, its errors)")
+ap.add_argument("--assets", default=None, help="directory of the image files a TextureImage without pixels names")
+ap.add_argument("--reference", action="store_true", help="float64 reference-order traversal instead of the fast mode")
+a = ap.parse_args()
+with open(a.scene, "rb") as f:
+    scene = phys.Scene.UnmarshalJSON(f.read(), strict=a.strict, asset_dir=a.assets or os.path.dirname(os.path.abspath(a.scene)))
+t0 = time.perf_counter()
+art = phys.Render(scene, abi.MODE_REFERENCE if a.reference else abi.MODE_FAST)  # validates the scene first, like phys.Render
+dt = time.perf_counter() - t0
+with open(a.out, "wb") as f:
+    f.write(obj.encode_png_rgba8(art.Image))
+st = art.Stats
+print(f"{st.Dx}x{st.Dy}: {st.TotalRays} rays ({st.RaysLeftScene} left the scene, {st.RaysExceededDepth} exceeded the depth) in {dt:.3f} s -> {a.out}")
