@@ -240,6 +240,13 @@ enum rt_mode {
     RT_MODE_FAST = 1
 };
 
+/* How a scene that lives on several devices (rt_init with n > 1) divides a frame among them. */
+enum rt_device_split {
+    RT_SPLIT_AUTO = 0,    /* samples when every device gets >= 256 of them and the frame has <= 2048 x 2048 pixels, else rows */
+    RT_SPLIT_ROWS = 1,    /* band b of 16 rows -> device b % n; each device copies its rows into the first device's film */
+    RT_SPLIT_SAMPLES = 2  /* device i renders the i-th run of sample indices of every pixel; the films are added on the first device */
+};
+
 typedef struct rt_render_opts { /* phys.RenderOptions, render.go:73-79 */
     int64_t seed;
     int32_t rays_per_pixel;
@@ -257,8 +264,8 @@ typedef struct rt_render_opts { /* phys.RenderOptions, render.go:73-79 */
      * sample_count == 0 means all of them. */
     int32_t sample_begin;
     int32_t sample_count;
-    int32_t reserved;
-    void* stream; /* hipStream_t to launch on; NULL = the null stream */
+    int32_t device_split; /* rt_device_split; ignored by a scene on one device */
+    void* stream; /* hipStream_t (of the first device) to launch on; NULL = the null stream */
 } rt_render_opts;
 
 typedef struct rt_stats { /* phys.RenderStats, render.go:38-45 */
@@ -269,7 +276,7 @@ typedef struct rt_stats { /* phys.RenderStats, render.go:38-45 */
     double render_seconds;        /* wall time of the call, scene already resident */
     double traverse_seconds;      /* sum of HIP-event time of the closest-hit traversal launches */
     uint64_t traverse_launches;
-    uint64_t traverse_rays;       /* rays those launches processed */
+    uint64_t traverse_rays;       /* rays those launches generated and traced (total_rays less culled_rays) */
     uint64_t culled_rays;         /* camera rays (counted in total_rays and rays_left_scene) that were not generated because their
                                      pixel lies outside the screen bounds of every node: they cannot hit anything */
 } rt_stats;
@@ -288,8 +295,14 @@ typedef struct rt_hit {
 typedef struct rt_scene rt_scene;
 
 /* Select the GPUs this process uses (device ordinals) and create per-device
- * state.  gpu_ids == NULL or n == 0 selects device 0.  Replaces nothing in the
- * reference (it is CPU only); called once from the Go package's init. */
+ * state.  gpu_ids == NULL or n == 0 selects device 0.  With n > 1 every scene
+ * created afterwards is replicated on all of them and rt_render / rt_render_film
+ * divide each frame among them (rt_device_split); the first device is where
+ * film_dev lives and where the frame is assembled.  An ordinal may be listed
+ * more than once: every entry gets a replica and a stream of its own, which lets
+ * a one-GPU machine run the multi-device path.  Replaces the reference's worker
+ * pool of runtime.NumCPU() goroutines (render.go:297-331); called once from the
+ * Go package's init. */
 int rt_init(const int* gpu_ids, int n);
 void rt_shutdown(void);
 

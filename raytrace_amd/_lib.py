@@ -78,16 +78,25 @@ def check(code: int, lib) -> None:
 
 
 def load(device: int = None) -> C.CDLL:
-    """Open the library and initialise it on `device` (default: LOCAL_RANK or 0)."""
+    """Open the library and initialise it on `device` (default: LOCAL_RANK or 0).  RT_DEVICES="0,1,..." selects
+    several devices for this process instead: every scene is then replicated on all of them and a frame is divided
+    among them inside the library (an ordinal may be repeated: see rt_init)."""
     global _LIB
     if _LIB is None:
         lib = open_library()
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
-        ids = (C.c_int * 1)(device)
-        check(lib.rt_init(ids, 1), lib)
+        if device is None and os.environ.get("RT_DEVICES"):
+            devices = [int(x) for x in os.environ["RT_DEVICES"].split(",")]
+        else:
+            devices = [int(os.environ.get("LOCAL_RANK", "0")) if device is None else device]
+        init(lib, devices)
         _LIB = lib
     return _LIB
+
+
+def init(lib, devices) -> None:
+    """rt_init(devices): may be called again to change the selection (scenes created before keep theirs)."""
+    ids = (C.c_int * len(devices))(*devices)
+    check(lib.rt_init(ids, len(devices)), lib)
 
 
 _HOST_LIB = None

@@ -32,6 +32,8 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_EMITTER, MAT_DEBUG_UV, MAT_DEBUG_
 CAM_PINHOLE, CAM_FOCUSABLE, CAM_ORTHOGRAPHIC, CAM_CALIBRATED = range(4)
 # rt_mode
 MODE_REFERENCE, MODE_FAST = range(2)
+# rt_device_split
+SPLIT_AUTO, SPLIT_ROWS, SPLIT_SAMPLES = range(3)
 
 D3 = C.c_double * 3
 
@@ -126,7 +128,7 @@ class RenderOpts(C.Structure):
         ("seed", C.c_int64), ("rays_per_pixel", C.c_int32), ("max_ray_depth", C.c_int32),
         ("dx", C.c_int32), ("dy", C.c_int32), ("mode", C.c_int32),
         ("band_rank", C.c_int32), ("band_world", C.c_int32), ("sample_begin", C.c_int32),
-        ("sample_count", C.c_int32), ("reserved", C.c_int32), ("stream", C.c_void_p),
+        ("sample_count", C.c_int32), ("device_split", C.c_int32), ("stream", C.c_void_p),
     ]
 
 

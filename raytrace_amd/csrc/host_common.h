@@ -14,8 +14,11 @@
 namespace rt {
 
 int fail(int code, const std::string& msg);  // records the thread-local message, returns code
+const std::string& last_error_text();        // this thread's message (threads of a multi-device render hand theirs to the caller)
 extern std::atomic<bool> g_initialized;
-extern int g_device;
+// The devices rt_init selected, in the caller's order.  The same ordinal may appear more than once: every entry gets a
+// replica and a stream of its own (a one-GPU machine can rehearse the multi-device path that way).
+extern std::vector<int> g_devices;
 
 #define HIP_TRY(expr)                                                                                             \
     do {                                                                                                          \
@@ -25,6 +28,9 @@ extern int g_device;
 
 struct DeviceBuffers {
     std::vector<void*> ptrs;
+    DeviceBuffers() = default;
+    DeviceBuffers(const DeviceBuffers&) = delete;
+    DeviceBuffers& operator=(const DeviceBuffers&) = delete;
     ~DeviceBuffers() {
         for (void* p : ptrs) (void)hipFree(p);
     }
@@ -54,11 +60,26 @@ void destroy_work(WorkBuffers* w);
 
 int make_camera(const rt_camera_desc& c, DCamera& d);
 
+// One device's copy of a scene: the flattened arrays, the queues of the wavefront loop and, on every device but the
+// first, a stream and a film of its own for its share of a multi-device render.
+struct Replica {
+    int device = 0;
+    DeviceBuffers mem;
+    DScene dev{};
+    WorkBuffers* work = nullptr;
+    hipStream_t stream = nullptr;  // created for replicas 1..n-1; replica 0 renders on the caller's stream
+    double* film = nullptr;        // replicas 1..n-1: this device's radiance sums of the frame being rendered
+    size_t film_doubles = 0;
+    double* inbox = nullptr;       // on the FIRST device: where this replica's film lands before it is added (sample split)
+    size_t inbox_doubles = 0;
+    hipEvent_t done = nullptr;     // recorded on `stream` when this replica's share of a frame is finished
+};
+
 }  // namespace rt
 
 struct rt_scene {
-    rt::DeviceBuffers mem;
-    rt::DScene dev{};
+    std::vector<std::unique_ptr<rt::Replica>> replicas;  // one per device of rt_init, in that order
+    uint64_t serial = 0;  // distinguishes scene handles over the life of the process (addresses are reused)
     std::vector<rt_bvh_info> bvh_info;
     // host copies of what the screen-space occupancy map of a camera is made from
     std::vector<double> node_box;        // DScene::node_box, 6 per node
@@ -66,15 +87,18 @@ struct rt_scene {
     std::vector<rt::DMesh> meshes;
     std::vector<rt::FastNode> fast_nodes;
     std::atomic<bool> cancel{false};
-    rt::WorkBuffers* work = nullptr;
     bool all_terminal = false;  // every material only emits: no shade / light-loop launches are ever needed
     bool mesh_only = false;     // every node is an untransformed mesh: kernels without the analytic shapes are used
-    int device = 0;
+    ~rt_scene();
 };
 
 namespace rt {
-// The wavefront loop for one process's share of the image; adds radiance sums into film (device).
-int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats);
-// Scratch buffers owned by the scene for rt_render (film sums, the 8-bit image and its pinned host copy), grown on demand.
-int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host);
+// The wavefront loop for one replica's share of the image; adds radiance sums into film (memory of that replica's device).
+// static_work: render with these buffers (the library's static scratch) instead of the replica's own; nothing is allocated then.
+int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats,
+                     WorkBuffers* static_work = nullptr);
+// The whole frame over every replica of the scene: bands of rows or runs of samples per device, combined on the first device.
+int render_all_devices(rt_scene* sc, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats);
+// Scratch buffers owned by a replica for rt_render (film sums, the 8-bit image and its pinned host copy), grown on demand.
+int scene_film(const rt_scene* sc, Replica& rep, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host);
 }  // namespace rt

@@ -55,6 +55,8 @@ void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int i
                   hipStream_t s);
 void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf, int mode, double* film, hipStream_t s);
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s);
+void launch_film_add(double* dst, const double* src, size_t n, hipStream_t s);  // dst[i] += src[i], both on the current device
+
 // src and dst: packed dx*dy RGBA8 device images; tmp: dx*dy*3 float64
 #ifdef RT_VISIT_STATS
 void debug_packet_stats(unsigned long long* out8, bool reset);  // diagnostics build only

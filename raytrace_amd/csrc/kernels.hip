@@ -12,6 +12,8 @@
 //   k_resolve   film sums -> 8-bit RGBA exactly as renderPixel quantises (render.go:218-224)
 #include "kernels.h"
 
+#include <mutex>
+
 #include "dev_bvh.h"
 #include "dev_shade.h"
 
@@ -978,6 +980,17 @@ void launch_filter(const uint8_t* src, int32_t w, int32_t h, int filter, double*
     const unsigned blocks = blocks_for((uint64_t)w * (uint64_t)h);
     hipLaunchKernelGGL(k_filter_h, dim3(blocks), dim3(kBlock), 0, s, reinterpret_cast<const uchar4*>(src), w, h, filter, tmp);
     hipLaunchKernelGGL(k_filter_v, dim3(blocks), dim3(kBlock), 0, s, tmp, w, h, filter, reinterpret_cast<uchar4*>(dst));
+}
+
+// dst += src over n float64 (the films of two devices that rendered different samples of the same pixels)
+__global__ void __launch_bounds__(kBlock) k_film_add(double* __restrict__ dst, const double* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+void launch_film_add(double* dst, const double* src, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_film_add, dim3(blocks_for(n)), dim3(kBlock), 0, s, dst, src, n);
 }
 
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s) {

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_common.h"
@@ -48,10 +49,11 @@ struct WorkBuffers {
     bool order_valid = false;
     uint32_t queue_off[8] = {}, queue_len[8] = {};
     uint64_t culled_pixels = 0;  // pixels of the tiles the schedule leaves out (outside the screen bounds of the scene)
+    bool is_static = false;      // the buffers live in the library's static scratch: nothing to allocate, grow or free
 };
 
 void destroy_work(WorkBuffers* w) {
-    if (!w) return;
+    if (!w || w->is_static) return;
     if (w->pool_base) (void)hipFree(w->pool_base);
     if (w->rgba) (void)hipFree(w->rgba);
     if (w->rgba_host) (void)hipHostFree(w->rgba_host);
@@ -105,10 +107,14 @@ hipError_t copy_rays(const RayQ& dst, uint64_t dst_at, const RayQ& src, uint64_t
     return e;
 }
 
-int ensure_work(rt_scene* sc) {
-    if (sc->work) return RT_OK;
-    auto* w = new WorkBuffers();
-    sc->work = w;
+int ensure_work(const rt_scene* sc, Replica& rep) {
+    if (rep.work) return RT_OK;
+    // built aside and published only when complete: a failed allocation must not leave half-made queues behind
+    struct Holder {
+        WorkBuffers* w = new WorkBuffers();
+        ~Holder() { destroy_work(w); }
+    } hold;
+    WorkBuffers* w = hold.w;
     w->q = (uint32_t)env_size("RT_QUEUE_RAYS", (size_t)1 << 25);
     if (w->q < 64 * 64) w->q = 64 * 64;
     const size_t q = w->q;
@@ -124,8 +130,8 @@ int ensure_work(rt_scene* sc) {
     const size_t ray_cap = rounds * 128, surf_cap = rounds * 64;
     // with two classes of rays (DScene::walk_classes) a class has stripes of its own, and of the trace waves that share a
     // grid x two write to the same stripe: a launch then takes half as many rays of a stripe
-    w->ray_stripes = sc->dev.walk_classes ? kRayStripes : kQueueStripes;
-    w->stripe_rays = (uint32_t)((sc->dev.walk_classes ? rounds / 2 : rounds) * 64 - 64);
+    w->ray_stripes = rep.dev.walk_classes ? kRayStripes : kQueueStripes;
+    w->stripe_rays = (uint32_t)((rep.dev.walk_classes ? rounds / 2 : rounds) * 64 - 64);
     HIP_TRY(w->mem.alloc((size_t)w->ray_stripes * ray_cap * kRayBytes, &rays0));
     HIP_TRY(w->mem.alloc((size_t)w->ray_stripes * ray_cap * kRayBytes, &rays1));
     HIP_TRY(w->mem.alloc(kQueueStripes * surf_cap * kSurfBytes, &surfs));
@@ -138,6 +144,8 @@ int ensure_work(rt_scene* sc) {
     HIP_TRY(w->mem.alloc(1, &w->d_queues));
     HIP_TRY(w->mem.alloc(1, &w->d_camera));
     HIP_TRY(hipMemcpy(w->d_queues, &w->queues, sizeof(Queues), hipMemcpyHostToDevice));
+    rep.work = w;
+    hold.w = nullptr;
     return RT_OK;
 }
 
@@ -350,9 +358,9 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& ge
 
 }  // namespace
 
-int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host) {
-    if (int rc = ensure_work(sc)) return rc;
-    WorkBuffers& w = *sc->work;
+int scene_film(const rt_scene* sc, Replica& rep, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host) {
+    if (int rc = ensure_work(sc, rep)) return rc;
+    WorkBuffers& w = *rep.work;
     const size_t px = (size_t)dx * dy;
     if (w.rgba_bytes < px * 4) {
         if (w.rgba) (void)hipFree(w.rgba);
@@ -377,7 +385,8 @@ int scene_film(rt_scene* sc, int dx, int dy, double** film, uint8_t** rgba, uint
     return RT_OK;
 }
 
-int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats) {
+int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats,
+                     WorkBuffers* static_work) {
     if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
     if (!sc || !camera || !o || !film) return fail(RT_ERR_INVALID, "null argument");
     // RenderOptions.Validate, render.go:81-98
@@ -394,13 +403,19 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
     if (rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "band_rank out of range");
     if (o->sample_count < 0 || o->sample_begin < 0 || (o->sample_count > 0 && o->sample_begin + o->sample_count > o->rays_per_pixel))
         return fail(RT_ERR_INVALID, "sample range outside [0, RaysPerPixel)");
-    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipSetDevice(rep.device));
     DCamera cam;
     if (int rc = make_camera(*camera, cam)) return rc;
-    if (int rc = ensure_work(sc)) return rc;
-    WorkBuffers& w = *sc->work;
+    if (static_work) {
+        if (!sc->all_terminal)
+            return fail(RT_ERR_UNSUPPORTED, "this scene scatters rays: its ray queues do not fit the static scratch (only scenes whose materials all just emit do)");
+    } else if (int rc = ensure_work(sc, rep)) {
+        return rc;
+    }
+    WorkBuffers& w = static_work ? *static_work : *rep.work;
     Queues& q = w.queues;
     hipStream_t stream = reinterpret_cast<hipStream_t>(o->stream);
+    if (static_work) HIP_TRY(hipMemcpyAsync(w.d_queues, &w.queues, sizeof(Queues), hipMemcpyHostToDevice, stream));
     sc->cancel.store(false);
     HIP_TRY(hipMemcpyAsync(w.d_camera, &cam, sizeof(DCamera), hipMemcpyHostToDevice, stream));  // pageable source: staged before the call returns
 
@@ -428,6 +443,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
 
     HIP_TRY(hipMemsetAsync(q.counters, 0, sizeof(Counters), stream));
     EventPool events;
+    const bool timed = static_work == nullptr;  // creating events allocates: the static path goes without launch timing
     uint64_t traverse_launches = 0, culled_rays = 0;
     Counters host{};
     uint64_t pool_top = 0;
@@ -446,9 +462,10 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
 
     // Cost-ordered schedule: worth a pilot pass when the frame has many tiles and more than a few samples.
     const std::string order_key = std::string(reinterpret_cast<const char*>(camera), sizeof(*camera)) + "|" + std::to_string(o->dx) + "x" +
-                                  std::to_string(o->dy) + "|" + std::to_string(rank) + "/" + std::to_string(world) + "|" + std::to_string(o->mode) + (want_cull ? "|c" : "|a");
+                                  std::to_string(o->dy) + "|" + std::to_string(rank) + "/" + std::to_string(world) + "|" + std::to_string(o->mode) +
+                                  (want_cull ? "|c" : "|a") + "|" + std::to_string(sc->serial);
     const bool want_order = tiles_total >= 2048 && std::getenv("RT_NO_TILE_ORDER") == nullptr;
-    if (want_order && (w.order_tiles != (size_t)tiles_total || !w.tile_cost)) {
+    if (want_order && !w.is_static && (w.order_tiles != (size_t)tiles_total || !w.tile_cost)) {
         if (w.tile_cost) (void)hipFree(w.tile_cost);
         if (w.tile_order) (void)hipFree(w.tile_order);
         w.tile_cost = nullptr;
@@ -473,23 +490,31 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         int s_count = 1;
         if (tiles_total * 64 <= paths_per_launch)
             s_count = (int)std::min<int64_t>(std::min(s_end - s0, pass_samples), paths_per_launch / std::max<int64_t>(tiles_total * 64, 1));
-        bool pilot = false;
-        if (want_order && !w.order_valid && tiles_total * 64 <= paths_per_launch && s_end - s0 >= 32) {  // fewer samples than that do not repay a pilot
-            pilot = true;  // a short pass over the whole frame that records what every tile costs
-            s_count = std::min(s_count, kPilotSamples);
-        }
-        // lanes per pixel: the widest power of two that keeps >= 90 % of the lanes busy over the rounds
         int log2_s = 0;
-        for (int l = 6; l > 0; l--) {
-            const int lanes = 1 << l, rounds = (s_count + lanes - 1) / lanes;
-            if (s_count * 10 >= rounds * lanes * 9) { log2_s = l; break; }
+        int64_t tiles_per_launch = 1;
+        auto plan = [&](int samples) {
+            // lanes per pixel: the widest power of two that keeps >= 90 % of the lanes busy over the rounds
+            log2_s = 0;
+            for (int l = 6; l > 0; l--) {
+                const int lanes = 1 << l, rounds = (samples + lanes - 1) / lanes;
+                if (samples * 10 >= rounds * lanes * 9) { log2_s = l; break; }
+            }
+            if (lanes_override >= 0) log2_s = std::min(lanes_override, 6);
+            // a tile takes 2^log2_s * ceil(samples / 2^log2_s) rounds of a wave; the queue stripes are sized for launches
+            // of at most q / 64 * 10 / 9 rounds (ensure_work), whatever the lanes are
+            const int64_t rounds_per_tile = ((int64_t)1 << log2_s) * ((samples + (1 << log2_s) - 1) >> log2_s);
+            tiles_per_launch = std::max<int64_t>(1, paths_per_launch / (64 * (int64_t)samples));
+            if (!sc->all_terminal) tiles_per_launch = std::max<int64_t>(1, std::min(tiles_per_launch, ((int64_t)w.q + 63) / 64 * 10 / 9 / rounds_per_tile));
+        };
+        // A pilot: a short pass over the WHOLE frame in one launch that records what every tile costs.  Fewer than 32
+        // samples to go do not repay it, and a frame that takes several launches per pass never runs from the schedule.
+        bool pilot = false;
+        if (want_order && !w.order_valid && tiles_total * 64 <= paths_per_launch && s_end - s0 >= 32) {
+            plan(std::min(s_count, kPilotSamples));
+            pilot = tiles_per_launch >= tiles_total;
         }
-        if (lanes_override >= 0) log2_s = std::min(lanes_override, 6);
-        // a tile takes 2^log2_s * ceil(s_count / 2^log2_s) rounds of a wave; the queue stripes are sized for launches
-        // of at most q / 64 * 10 / 9 rounds (ensure_work), whatever the lanes are
-        const int64_t rounds_per_tile = ((int64_t)1 << log2_s) * ((s_count + (1 << log2_s) - 1) >> log2_s);
-        int64_t tiles_per_launch = std::max<int64_t>(1, paths_per_launch / (64 * (int64_t)s_count));
-        if (!sc->all_terminal) tiles_per_launch = std::max<int64_t>(1, std::min(tiles_per_launch, ((int64_t)w.q + 63) / 64 * 10 / 9 / rounds_per_tile));
+        if (pilot) s_count = std::min(s_count, kPilotSamples);
+        else plan(s_count);
         for (int64_t t0 = 0; t0 < tiles_total; t0 += tiles_per_launch) {
             if (sc->cancel.load()) {
                 (void)hipStreamSynchronize(stream);
@@ -515,11 +540,13 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
             if (pass.cost) HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
             if (int rc = reset_cursors()) return rc;
             EventPair* ev = nullptr;
-            HIP_TRY(events.next(&ev));
-            HIP_TRY(hipEventRecord(ev->a, stream));
-            launch_primary(sc->dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream);
+            if (timed) {
+                HIP_TRY(events.next(&ev));
+                HIP_TRY(hipEventRecord(ev->a, stream));
+            }
+            launch_primary(rep.dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream);
             if (pass.order) culled_rays += w.culled_pixels * (uint64_t)s_count;  // tiles the schedule leaves out: nothing to trace
-            HIP_TRY(hipEventRecord(ev->b, stream));
+            if (timed) HIP_TRY(hipEventRecord(ev->b, stream));
             HIP_TRY(hipGetLastError());
             traverse_launches++;
             if (sc->all_terminal) {
@@ -550,25 +577,33 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                     n_surf += surf_n.n[k];
                 }
                 if (n_surf > 0) {
-                    launch_direct(sc->dev, q, surf_n, o->mode, film, stream);
-                    shadow_rays += n_surf * (uint64_t)sc->dev.n_lights;  // one occlusion ray per surface point and light
+                    launch_direct(rep.dev, q, surf_n, o->mode, film, stream);
+                    shadow_rays += n_surf * (uint64_t)rep.dev.n_lights;  // one occlusion ray per surface point and light
                     HIP_TRY(hipGetLastError());
                 }
                 // This launch takes at most q rays in all and stripe_rays of a stripe; the rest is parked on the overflow
-                // stack (bounded by q * (MaxRayDepth + 1)) and comes back when a generation has died out.
+                // stack (it grows on demand: a generation parks at most 2 q rays, and at most MaxRayDepth + 1 generations
+                // are parked at a time) and comes back when a generation has died out.
                 uint64_t n = 0;
                 for (int k = 0; k < w.ray_stripes; k++) {
                     const uint32_t keep = (uint32_t)std::min<uint64_t>(std::min(rays_n.n[k], w.stripe_rays), (uint64_t)w.q - n);
                     const uint64_t excess = rays_n.n[k] - keep;
                     if (excess) {
-                        if (!w.pool_base) {
-                            const uint64_t want = (uint64_t)w.q * (uint64_t)(o->max_ray_depth + 1);
-                            hipError_t pe = hipMalloc(&w.pool_base, want * kRayBytes);
-                            if (pe != hipSuccess) { w.pool_base = nullptr; return fail(RT_ERR_NOMEM, hipGetErrorString(pe)); }
-                            carve(w.pool, w.pool_base, want);
+                        if (pool_top + excess > w.pool_capacity) {  // grow: a new stack, the parked rays moved over
+                            const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(2 * w.pool_capacity, pool_top + excess), 2 * (uint64_t)w.q);
+                            void* bigger = nullptr;
+                            hipError_t pe = hipMalloc(&bigger, want * kRayBytes);
+                            if (pe != hipSuccess) return fail(RT_ERR_NOMEM, std::string("overflow stack of ") + std::to_string(want) + " rays: " + hipGetErrorString(pe));
+                            RayQ grown{};
+                            carve(grown, bigger, want);
+                            if (pool_top) pe = copy_rays(grown, 0, w.pool, 0, pool_top, stream);
+                            if (pe == hipSuccess) pe = hipStreamSynchronize(stream);
+                            if (pe != hipSuccess) { (void)hipFree(bigger); return fail(RT_ERR_DEVICE, hipGetErrorString(pe)); }
+                            if (w.pool_base) (void)hipFree(w.pool_base);
+                            w.pool_base = bigger;
+                            w.pool = grown;
                             w.pool_capacity = want;
                         }
-                        if (pool_top + excess > w.pool_capacity) return fail(RT_ERR_NOMEM, "ray pool exhausted");
                         HIP_TRY(copy_rays(w.pool, pool_top, q.rays[cur], (uint64_t)k * q.ray_stripe_cap + keep, excess, stream));
                         pool_top += excess;
                     }
@@ -588,7 +623,7 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
                 if (int rc = reset_cursors()) return rc;
                 HIP_TRY(events.next(&ev));
                 HIP_TRY(hipEventRecord(ev->a, stream));
-                launch_trace(sc->dev, pass, q, cur, rays_n, o->mode, sc->mesh_only, film, stream);
+                launch_trace(rep.dev, pass, q, cur, rays_n, o->mode, sc->mesh_only, film, stream);
                 launched_rays += n;
                 HIP_TRY(hipEventRecord(ev->b, stream));
                 HIP_TRY(hipGetLastError());
@@ -635,8 +670,150 @@ int render_into_film(rt_scene* sc, const rt_camera_desc* camera, const rt_render
         stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         stats->traverse_seconds = events.ms * 1e-3;
         stats->traverse_launches = traverse_launches;
-        stats->traverse_rays = total + culled_rays;  // every counted ray was settled by exactly one of the timed launches
+        stats->traverse_rays = total;  // every ray a kernel generated and traced was settled by exactly one of the timed launches
         stats->culled_rays = culled_rays;
+    }
+    return RT_OK;
+}
+
+// ---- one frame over several devices ----------------------------------------------------------------------------
+//
+// The reference renders a frame with NumCPU goroutines that pull 16x16 tiles from one channel and write disjoint
+// pixels of one image (render.go:297-331).  Here every device of rt_init holds a replica of the scene and renders a
+// share of the frame into a film in its own memory, driven by a host thread of its own:
+//   rows     band b of 16 rows (the reference's tile height) goes to device b % n; afterwards every device copies its
+//            bands into the first device's film over its own link (disjoint rows: the frame is exact);
+//   samples  device i renders the i-th run of sample indices of EVERY pixel (the random streams are keyed by pixel
+//            and sample index, so the samples are the ones a single device would draw); the films are copied to the
+//            first device and added there.  For frames with few pixels and many samples per pixel.
+// The first device renders straight into the caller's film on the caller's stream.
+
+namespace {
+
+struct Share {
+    int rc = RT_OK;
+    std::string error;
+    rt_stats stats{};
+};
+
+int ensure_peer_buffers(Replica& first, Replica& rep, size_t film_doubles, bool want_inbox) {
+    if (rep.film_doubles < film_doubles) {
+        HIP_TRY(hipSetDevice(rep.device));
+        if (rep.film) (void)hipFree(rep.film);
+        rep.film = nullptr;
+        rep.film_doubles = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rep.film), film_doubles * sizeof(double)));
+        rep.film_doubles = film_doubles;
+    }
+    if (want_inbox && rep.inbox_doubles < film_doubles) {
+        HIP_TRY(hipSetDevice(first.device));
+        if (rep.inbox) (void)hipFree(rep.inbox);
+        rep.inbox = nullptr;
+        rep.inbox_doubles = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rep.inbox), film_doubles * sizeof(double)));
+        rep.inbox_doubles = film_doubles;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+int render_all_devices(rt_scene* sc, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats) {
+    if (!sc || !camera || !o || !film) return fail(RT_ERR_INVALID, "null argument");
+    const int n = (int)sc->replicas.size();
+    if (n == 1) return render_into_film(sc, *sc->replicas[0], camera, o, film, stats);
+    if (o->band_world > 1) return fail(RT_ERR_INVALID, "band_rank / band_world cannot be combined with a scene that lives on several devices");
+    if (o->dx <= 0 || o->dy <= 0 || o->rays_per_pixel <= 0) return fail(RT_ERR_INVALID, "bad Dx / Dy / RaysPerPixel must be positive");
+    if (o->sample_count < 0 || o->sample_begin < 0 || (o->sample_count > 0 && o->sample_begin + o->sample_count > o->rays_per_pixel))
+        return fail(RT_ERR_INVALID, "sample range outside [0, RaysPerPixel)");
+    const int s_first = o->sample_count > 0 ? o->sample_begin : 0;
+    const int s_total = o->sample_count > 0 ? o->sample_count : o->rays_per_pixel;
+    const size_t film_doubles = (size_t)o->dx * o->dy * 3;
+    int split = o->device_split;
+    if (split != RT_SPLIT_AUTO && split != RT_SPLIT_ROWS && split != RT_SPLIT_SAMPLES) return fail(RT_ERR_INVALID, "unknown device_split");
+    if (split == RT_SPLIT_AUTO)  // few pixels, many samples: every device takes a run of samples (a film of at most 100 MB travels)
+        split = (s_total / n >= 256 && (int64_t)o->dx * o->dy <= (int64_t)2048 * 2048) ? RT_SPLIT_SAMPLES : RT_SPLIT_ROWS;
+    if (split == RT_SPLIT_SAMPLES && s_total < n) split = RT_SPLIT_ROWS;
+    Replica& first = *sc->replicas[0];
+    for (int i = 1; i < n; i++)
+        if (int rc = ensure_peer_buffers(first, *sc->replicas[(size_t)i], film_doubles, split == RT_SPLIT_SAMPLES)) return rc;
+    HIP_TRY(hipSetDevice(first.device));
+    hipStream_t stream0 = reinterpret_cast<hipStream_t>(o->stream);
+    // what the caller queued before this call (zeroing the film) must have happened before a peer writes into the film
+    HIP_TRY(hipEventRecord(first.done, stream0));
+
+    const auto t_start = std::chrono::steady_clock::now();
+    std::vector<Share> shares((size_t)n);
+    auto run = [&](int i) {
+        Share& sh = shares[(size_t)i];
+        Replica& rep = *sc->replicas[(size_t)i];
+        auto fail_here = [&](hipError_t e, const char* what) {
+            sh.rc = RT_ERR_DEVICE;
+            sh.error = std::string(what) + ": " + hipGetErrorString(e);
+        };
+        hipError_t e = hipSetDevice(rep.device);
+        if (e != hipSuccess) return fail_here(e, "hipSetDevice");
+        rt_render_opts mine = *o;
+        mine.band_rank = 0;
+        mine.band_world = 1;
+        if (split == RT_SPLIT_ROWS) {
+            mine.band_rank = i;
+            mine.band_world = n;
+        } else {  // the i-th of n nearly equal runs of the sample indices
+            const int lo = (int)((int64_t)s_total * i / n), hi = (int)((int64_t)s_total * (i + 1) / n);
+            mine.sample_begin = s_first + lo;
+            mine.sample_count = hi - lo;
+        }
+        double* target = film;
+        if (i > 0) {
+            mine.stream = rep.stream;
+            target = rep.film;
+            e = hipMemsetAsync(target, 0, film_doubles * sizeof(double), rep.stream);
+            if (e != hipSuccess) return fail_here(e, "hipMemsetAsync");
+        }
+        sh.rc = render_into_film(sc, rep, camera, &mine, target, &sh.stats);
+        if (sh.rc != RT_OK) { sh.error = last_error_text(); return; }
+        if (i == 0) return;
+        // render_into_film has synchronised rep.stream: the share is complete.  Send it to the first device.
+        e = hipStreamWaitEvent(rep.stream, first.done, 0);
+        if (e != hipSuccess) return fail_here(e, "hipStreamWaitEvent");
+        if (split == RT_SPLIT_ROWS) {
+            const size_t row_doubles = (size_t)o->dx * 3;
+            for (int band = i; band * 16 < o->dy && e == hipSuccess; band += n) {
+                const size_t rows = (size_t)std::min(16, o->dy - band * 16), off = (size_t)band * 16 * row_doubles;
+                e = hipMemcpyPeerAsync(film + off, first.device, rep.film + off, rep.device, rows * row_doubles * sizeof(double), rep.stream);
+            }
+        } else {
+            e = hipMemcpyPeerAsync(rep.inbox, first.device, rep.film, rep.device, film_doubles * sizeof(double), rep.stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(rep.stream);
+        if (e != hipSuccess) return fail_here(e, "copy to the first device");
+    };
+    std::vector<std::thread> threads;
+    for (int i = 1; i < n; i++) threads.emplace_back(run, i);
+    run(0);
+    for (std::thread& t : threads) t.join();
+    HIP_TRY(hipSetDevice(first.device));
+    for (const Share& sh : shares)
+        if (sh.rc != RT_OK) return fail(sh.rc, sh.error);
+    if (split == RT_SPLIT_SAMPLES) {
+        for (int i = 1; i < n; i++) launch_film_add(film, sc->replicas[(size_t)i]->inbox, film_doubles, stream0);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(stream0));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (const Share& sh : shares) {
+            stats->total_rays += sh.stats.total_rays;
+            stats->rays_exceeded_depth += sh.stats.rays_exceeded_depth;
+            stats->rays_left_scene += sh.stats.rays_left_scene;
+            stats->shadow_rays += sh.stats.shadow_rays;
+            stats->traverse_launches += sh.stats.traverse_launches;
+            stats->traverse_rays += sh.stats.traverse_rays;
+            stats->culled_rays += sh.stats.culled_rays;
+            stats->traverse_seconds = std::max(stats->traverse_seconds, sh.stats.traverse_seconds);  // the slowest device's launches
+        }
+        stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     }
     return RT_OK;
 }

@@ -22,12 +22,14 @@ namespace rt {
 
 thread_local std::string tl_error;
 std::atomic<bool> g_initialized{false};
-int g_device = 0;
+std::vector<int> g_devices;
+std::atomic<uint64_t> g_scene_serial{0};
 
 int fail(int code, const std::string& msg) {
     tl_error = msg;
     return code;
 }
+const std::string& last_error_text() { return tl_error; }
 
 }  // namespace rt
 
@@ -140,6 +142,22 @@ int check_shape_ref(const rt_scene_desc& d, int kind, int index, int depth) {
 
 }  // namespace
 
+rt_scene::~rt_scene() {
+    if (replicas.empty()) return;
+    (void)hipSetDevice(replicas[0]->device);
+    for (auto& rep : replicas)
+        if (rep->inbox) (void)hipFree(rep->inbox);  // the inboxes of all replicas live on the first device
+    for (auto& rep : replicas) {
+        (void)hipSetDevice(rep->device);
+        rt::destroy_work(rep->work);
+        if (rep->film) (void)hipFree(rep->film);
+        if (rep->stream) (void)hipStreamDestroy(rep->stream);
+        if (rep->done) (void)hipEventDestroy(rep->done);
+        rep.reset();  // frees the scene arrays with this replica's device current
+    }
+    if (!rt::g_devices.empty()) (void)hipSetDevice(rt::g_devices[0]);
+}
+
 extern "C" {
 
 const char* rt_last_error(void) { return rt::tl_error.c_str(); }
@@ -148,14 +166,29 @@ int rt_init(const int* gpu_ids, int n) {
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (count <= 0) return fail(RT_ERR_DEVICE, "no HIP device visible");
-    int dev = (gpu_ids && n > 0) ? gpu_ids[0] : 0;
-    if (dev < 0 || dev >= count) return fail(RT_ERR_INVALID, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(dev));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
-        return fail(RT_ERR_UNSUPPORTED, std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName);
-    g_device = dev;
+    std::vector<int> devices;
+    if (gpu_ids && n > 0) devices.assign(gpu_ids, gpu_ids + n);
+    else devices.push_back(0);
+    if (devices.size() > 64) return fail(RT_ERR_INVALID, "more than 64 devices");
+    for (int dev : devices) {
+        if (dev < 0 || dev >= count) return fail(RT_ERR_INVALID, "device ordinal out of range");
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            return fail(RT_ERR_UNSUPPORTED, std::string("this library is built for gfx950 only, device is ") + prop.gcnArchName);
+    }
+    for (int dev : devices) {
+        HIP_TRY(hipSetDevice(dev));
+        for (int other : devices) {  // films travel between the devices: direct access where the links allow it
+            int can = 0;
+            if (other == dev || hipDeviceCanAccessPeer(&can, dev, other) != hipSuccess || !can) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(RT_ERR_DEVICE, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    }
+    HIP_TRY(hipSetDevice(devices[0]));
+    g_devices = devices;
     g_initialized = true;
     return RT_OK;
 }
@@ -257,7 +290,6 @@ Bounds shape_bounds(int kind, int index, const std::vector<DSphere>& spheres, co
 int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
     if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(g_device));
     // the array-level checks of Scene.Validate (scene.go:29-79) and of each Validate() it calls
     for (uint64_t i = 0; i < d->n_nodes; i++) {
         const rt_node& n = d->nodes[i];
@@ -307,10 +339,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     for (uint64_t i = 0; i < d->n_lights; i++)
         if (d->lights[i].intensity[0] < 0 || d->lights[i].intensity[1] < 0 || d->lights[i].intensity[2] < 0)
             return fail(RT_ERR_INVALID, "invalid PointLight RadiantIntensity (should be non-negative)");
-    if (d->n_nodes > 0x7fffffffull || d->n_lights > 65535) return fail(RT_ERR_UNSUPPORTED, "too many nodes or lights");
+    // the light loop's launch has one grid row per (light, queue stripe), and a grid has at most 65535 rows
+    if (d->n_nodes > 0x7fffffffull || d->n_lights > 65535 / kQueueStripes)
+        return fail(RT_ERR_UNSUPPORTED, "too many nodes or lights (at most " + std::to_string(65535 / kQueueStripes) + " point lights)");
 
     std::unique_ptr<rt_scene> sc(new rt_scene());
-    sc->device = g_device;
+    sc->serial = ++g_scene_serial;
     std::vector<DNode> nodes(d->n_nodes);
     for (uint64_t i = 0; i < d->n_nodes; i++) nodes[i] = {d->nodes[i].shape_kind, d->nodes[i].shape_index, d->nodes[i].material, 0};
     std::vector<DSphere> spheres(d->n_spheres);
@@ -385,34 +419,6 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<rt_material> materials(d->materials, d->materials + d->n_materials);
     std::vector<rt_texture> textures(d->textures, d->textures + d->n_textures);
     std::vector<rt_light> lights(d->lights, d->lights + d->n_lights);
-    std::vector<DImage> images(d->n_images);
-    for (uint64_t i = 0; i < d->n_images; i++) {
-        const rt_image& im = d->images[i];
-        const size_t bytes = (size_t)im.width * im.height * (im.format == RT_IMG_RGBA16 ? 8 : 4);
-        uint8_t* px = nullptr;
-        HIP_TRY(sc->mem.alloc(bytes, &px));
-        HIP_TRY(hipMemcpy(px, im.pixels, bytes, hipMemcpyHostToDevice));
-        images[i] = {px, im.width, im.height, im.format, 0};
-    }
-    DScene& dev = sc->dev;
-    HIP_TRY(sc->mem.upload(nodes, &dev.nodes));
-    HIP_TRY(sc->mem.upload(spheres, &dev.spheres));
-    HIP_TRY(sc->mem.upload(quads, &dev.quads));
-    HIP_TRY(sc->mem.upload(cyls, &dev.cylinders));
-    HIP_TRY(sc->mem.upload(tris, &dev.tris));
-    HIP_TRY(sc->mem.upload(xforms, &dev.xforms));
-    HIP_TRY(sc->mem.upload(meshes, &dev.meshes));
-    HIP_TRY(sc->mem.upload(ref_nodes, &dev.ref_nodes));
-    HIP_TRY(sc->mem.upload(fast_nodes, &dev.fast_nodes));
-    HIP_TRY(sc->mem.upload(prim_pos, &dev.prim_pos));
-    HIP_TRY(sc->mem.upload(prim_tri32, &dev.prim_tri32));
-    HIP_TRY(sc->mem.upload(prim_face, &dev.prim_face));
-    HIP_TRY(sc->mem.upload(face_uv, &dev.face_uv));
-    HIP_TRY(sc->mem.upload(materials, &dev.materials));
-    HIP_TRY(sc->mem.upload(textures, &dev.textures));
-    HIP_TRY(sc->mem.upload(images, &dev.images));
-    HIP_TRY(sc->mem.upload(lights, &dev.lights));
-    HIP_TRY(sc->mem.upload(node_box, &dev.node_box));
     sc->node_box = node_box;
     sc->nodes = nodes;
     sc->meshes = meshes;
@@ -423,10 +429,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     sc->mesh_only = d->n_nodes > 0;
     for (const DNode& n : nodes)
         if (n.kind != RT_SHAPE_MESH) sc->mesh_only = false;
-    dev.n_nodes = (int32_t)d->n_nodes;
-    dev.n_lights = (int32_t)d->n_lights;
-    dev.stack_pairs = stack_pairs;
-    dev.n_meshes = (int32_t)d->n_meshes;
+    DScene proto{};
+    proto.n_nodes = (int32_t)d->n_nodes;
+    proto.n_lights = (int32_t)d->n_lights;
+    proto.stack_pairs = stack_pairs;
+    proto.n_meshes = (int32_t)d->n_meshes;
     {   // bounds of every node that holds a mesh (directly or under transforms): rays that miss them never walk a tree
         bool any = false;
         double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -438,18 +445,54 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             }
             any = true;
         }
-        for (int k = 0; k < 3; k++) { dev.walk_box[k] = lo[k]; dev.walk_box[3 + k] = hi[k]; }
-        dev.walk_classes = (any && d->n_meshes > 0 && !sc->mesh_only && std::getenv("RT_NO_RAY_CLASSES") == nullptr) ? 1 : 0;
-        dev.pad = 0;
+        for (int k = 0; k < 3; k++) { proto.walk_box[k] = lo[k]; proto.walk_box[3 + k] = hi[k]; }
+        proto.walk_classes = (any && d->n_meshes > 0 && !sc->mesh_only && std::getenv("RT_NO_RAY_CLASSES") == nullptr) ? 1 : 0;
+        proto.pad = 0;
     }
+    // One host build, one upload per device: every device of rt_init gets the same arrays.
+    for (size_t r = 0; r < g_devices.size(); r++) {
+        std::unique_ptr<Replica> rep(new Replica());
+        rep->device = g_devices[r];
+        HIP_TRY(hipSetDevice(rep->device));
+        std::vector<DImage> images(d->n_images);
+        for (uint64_t i = 0; i < d->n_images; i++) {
+            const rt_image& im = d->images[i];
+            const size_t bytes = (size_t)im.width * im.height * (im.format == RT_IMG_RGBA16 ? 8 : 4);
+            uint8_t* px = nullptr;
+            HIP_TRY(rep->mem.alloc(bytes, &px));
+            HIP_TRY(hipMemcpy(px, im.pixels, bytes, hipMemcpyHostToDevice));
+            images[i] = {px, im.width, im.height, im.format, 0};
+        }
+        DScene& dev = rep->dev;
+        dev = proto;
+        HIP_TRY(rep->mem.upload(nodes, &dev.nodes));
+        HIP_TRY(rep->mem.upload(spheres, &dev.spheres));
+        HIP_TRY(rep->mem.upload(quads, &dev.quads));
+        HIP_TRY(rep->mem.upload(cyls, &dev.cylinders));
+        HIP_TRY(rep->mem.upload(tris, &dev.tris));
+        HIP_TRY(rep->mem.upload(xforms, &dev.xforms));
+        HIP_TRY(rep->mem.upload(meshes, &dev.meshes));
+        HIP_TRY(rep->mem.upload(ref_nodes, &dev.ref_nodes));
+        HIP_TRY(rep->mem.upload(fast_nodes, &dev.fast_nodes));
+        HIP_TRY(rep->mem.upload(prim_pos, &dev.prim_pos));
+        HIP_TRY(rep->mem.upload(prim_tri32, &dev.prim_tri32));
+        HIP_TRY(rep->mem.upload(prim_face, &dev.prim_face));
+        HIP_TRY(rep->mem.upload(face_uv, &dev.face_uv));
+        HIP_TRY(rep->mem.upload(materials, &dev.materials));
+        HIP_TRY(rep->mem.upload(textures, &dev.textures));
+        HIP_TRY(rep->mem.upload(images, &dev.images));
+        HIP_TRY(rep->mem.upload(lights, &dev.lights));
+        HIP_TRY(rep->mem.upload(node_box, &dev.node_box));
+        HIP_TRY(hipEventCreateWithFlags(&rep->done, hipEventDisableTiming));
+        if (r > 0) HIP_TRY(hipStreamCreateWithFlags(&rep->stream, hipStreamNonBlocking));
+        sc->replicas.push_back(std::move(rep));
+    }
+    HIP_TRY(hipSetDevice(g_devices[0]));
     *out = sc.release();
     return RT_OK;
 }
 
 void rt_scene_destroy(rt_scene* scene) {
-    if (!scene) return;
-    (void)hipSetDevice(scene->device);
-    destroy_work(scene->work);
     delete scene;
 }
 
@@ -485,13 +528,15 @@ void rt_cancel(rt_scene* scene) {
 }
 
 int rt_render_film(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* film_dev, rt_stats* stats) {
-    return render_into_film(scene, camera, opts, film_dev, stats);
+    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    return render_all_devices(scene, camera, opts, film_dev, stats);
 }
 
 int rt_film_resolve(const double* film_dev, int32_t dx, int32_t dy, int32_t rays_per_pixel, uint8_t* rgba_out, size_t stride, void* stream_) {
     if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
     if (!film_dev || !rgba_out || dx <= 0 || dy <= 0 || rays_per_pixel <= 0 || stride < (size_t)dx * 4) return fail(RT_ERR_INVALID, "bad argument");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(g_devices[0]));
     uint8_t* rgba = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&rgba), (size_t)dx * dy * 4));
     launch_resolve(film_dev, dx, dy, rays_per_pixel, rgba, stream);
@@ -509,7 +554,7 @@ int rt_apply_filter(const uint8_t* rgba_in, size_t stride_in, int32_t dx, int32_
     if (!rgba_in || !rgba_out || dx <= 0 || dy <= 0 || stride_in < (size_t)dx * 4 || stride_out < (size_t)dx * 4)
         return fail(RT_ERR_INVALID, "bad argument");
     if (filter < RT_RECON_BOX || filter > RT_RECON_MITCHELL) return fail(RT_ERR_INVALID, "unknown reconstruction filter");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(g_devices[0]));
     const size_t row = (size_t)dx * 4, px = (size_t)dx * dy;
     DeviceBuffers tmp;
     uint8_t *src = nullptr, *dst = nullptr;
@@ -528,15 +573,17 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opt
     if (!scene || !opts || !rgba_out) return fail(RT_ERR_INVALID, "null argument");
     if (opts->dx <= 0 || opts->dy <= 0) return fail(RT_ERR_INVALID, "bad Dx / Dy must be positive");
     if (stride < (size_t)opts->dx * 4) return fail(RT_ERR_INVALID, "stride smaller than a row");
-    HIP_TRY(hipSetDevice(scene->device));
+    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    Replica& first = *scene->replicas[0];
+    HIP_TRY(hipSetDevice(first.device));
     double* film = nullptr;
     uint8_t *rgba = nullptr, *rgba_host = nullptr;
-    if (int rc = scene_film(scene, opts->dx, opts->dy, &film, &rgba, &rgba_host)) return rc;
+    if (int rc = scene_film(scene, first, opts->dx, opts->dy, &film, &rgba, &rgba_host)) return rc;
     const size_t n = (size_t)opts->dx * opts->dy * 3;
     hipStream_t stream = reinterpret_cast<hipStream_t>(opts->stream);
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemsetAsync(film, 0, n * sizeof(double), stream));
-    if (int rc = render_into_film(scene, camera, opts, film, stats)) return rc;
+    if (int rc = render_all_devices(scene, camera, opts, film, stats)) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     launch_resolve(film, opts->dx, opts->dy, opts->rays_per_pixel, rgba, stream);
     // device -> pinned staging buffer at full PCIe rate, then rows into the caller's (pageable, possibly strided) image
@@ -558,7 +605,7 @@ int rt_intersect_batch(rt_scene* scene, const double* o, const double* d, uint64
     if (!scene || (n && (!o || !d || !hits))) return fail(RT_ERR_INVALID, "null argument");
     if (mode != RT_MODE_REFERENCE && mode != RT_MODE_FAST) return fail(RT_ERR_INVALID, "unknown mode");
     if (n == 0) return RT_OK;
-    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipSetDevice(scene->replicas[0]->device));
     DeviceBuffers tmp;
     double *od = nullptr, *dd = nullptr;
     rt_hit* hd = nullptr;
@@ -567,7 +614,7 @@ int rt_intersect_batch(rt_scene* scene, const double* o, const double* d, uint64
     HIP_TRY(tmp.alloc(n, &hd));
     HIP_TRY(hipMemcpy(od, o, n * 24, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dd, d, n * 24, hipMemcpyHostToDevice));
-    launch_intersect_batch(scene->dev, od, dd, n, tmin, tmax, mode, hd, nullptr);
+    launch_intersect_batch(scene->replicas[0]->dev, od, dd, n, tmin, tmax, mode, hd, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hits, hd, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
     return RT_OK;
@@ -578,7 +625,7 @@ int rt_cast_batch(const rt_camera_desc* camera, const double* st, const uint32_t
     if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
     if (!camera || (n && (!st || !pixel_sample || !o_out || !d_out))) return fail(RT_ERR_INVALID, "null argument");
     if (n == 0) return RT_OK;
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(g_devices[0]));
     DCamera cam;
     if (int rc = make_camera(*camera, cam)) return rc;
     DeviceBuffers tmp;

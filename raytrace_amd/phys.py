@@ -805,9 +805,9 @@ def camera_desc(cam) -> abi.CameraDesc:
 
 
 def render_opts(o: RenderOptions, mode=abi.MODE_FAST, band_rank=0, band_world=1, stream=None, sample_begin=0,
-                sample_count=0) -> abi.RenderOpts:
+                sample_count=0, device_split=abi.SPLIT_AUTO) -> abi.RenderOpts:
     return abi.RenderOpts(int(o.Seed), int(o.RaysPerPixel), int(o.MaxRayDepth), int(o.Dx), int(o.Dy), int(mode),
-                          int(band_rank), int(band_world), int(sample_begin), int(sample_count), 0, stream)
+                          int(band_rank), int(band_world), int(sample_begin), int(sample_count), int(device_split), stream)
 
 
 # ---- the render entry point -------------------------------------------------------------
@@ -840,12 +840,12 @@ class DeviceScene:
         except Exception:
             pass
 
-    def render(self, camera, options: RenderOptions, mode=abi.MODE_FAST) -> RenderArtifact:
+    def render(self, camera, options: RenderOptions, mode=abi.MODE_FAST, device_split=abi.SPLIT_AUTO) -> RenderArtifact:
         from . import _lib
         img = np.zeros((options.Dy, options.Dx, 4), dtype=np.uint8)
         st = abi.Stats()
         cd = camera_desc(camera)
-        ro = render_opts(options, mode)
+        ro = render_opts(options, mode, device_split=device_split)
         _lib.check(self._lib.rt_render(self.handle, C.byref(cd), C.byref(ro), img.ctypes.data_as(C.POINTER(C.c_uint8)),
                                        options.Dx * 4, C.byref(st)), self._lib)
         return RenderArtifact(img, stats_from(st, options))

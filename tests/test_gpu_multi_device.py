@@ -1,0 +1,75 @@
+"""A scene replicated on several devices inside the library (rt_init with n > 1): rt_render divides the frame among
+them by rows or by samples and must give the single-device image.  On a machine with one GPU the two replicas both
+live on device 0 (rt_init accepts a repeated ordinal for exactly this), which runs the same threads, streams, peer
+copies and the film sum."""
+import numpy as np
+import pytest
+
+from raytrace_amd import abi, phys, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def two_devices():
+    import torch
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    devices = [0, 1] if torch.cuda.device_count() >= 2 else [0, 0]
+    yield lib, devices
+    _lib.init(lib, [0])
+
+
+def _render(sc, split=abi.SPLIT_AUTO, mode=abi.MODE_FAST):
+    with phys.DeviceScene(sc) as dev:
+        return dev.render(sc.Camera[0], sc.RenderOptions, mode, split)
+
+
+def test_emitter_scene_on_two_replicas_gives_the_single_device_bytes(two_devices):
+    from raytrace_amd import _lib
+    lib, devices = two_devices
+    sc = scenes.scan(level=5, dx=512, dy=392, spp=40, tex_size=256)  # 392 rows: the last band is a partial one
+    one = _render(sc)
+    _lib.init(lib, devices)
+    rows = _render(sc, abi.SPLIT_ROWS)
+    assert np.array_equal(rows.Image, one.Image)  # disjoint rows are copied: exact
+    for f in ("TotalRays", "RaysLeftScene", "RaysExceededDepth"):
+        assert getattr(rows.Stats, f) == getattr(one.Stats, f), f
+    samples = _render(sc, abi.SPLIT_SAMPLES)
+    diff = np.abs(samples.Image.astype(int) - one.Image.astype(int))  # the same samples, summed in another order
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    assert samples.Stats.TotalRays == one.Stats.TotalRays
+    auto = _render(sc)  # 20 samples per device: rows
+    assert np.array_equal(auto.Image, one.Image)
+    ref = _render(sc, abi.SPLIT_ROWS, abi.MODE_REFERENCE)
+    diff = np.abs(ref.Image.astype(int) - one.Image.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+
+
+def test_scattering_scene_on_two_replicas(two_devices):
+    from raytrace_amd import _lib
+    lib, devices = two_devices
+    sc = scenes.cornell(dx=128, dy=96, spp=16)
+    one = _render(sc)
+    _lib.init(lib, devices)
+    for split in (abi.SPLIT_ROWS, abi.SPLIT_SAMPLES):
+        two = _render(sc, split)
+        assert two.Stats.TotalRays == one.Stats.TotalRays and two.Stats.ShadowRays == one.Stats.ShadowRays
+        diff = np.abs(two.Image.astype(int) - one.Image.astype(int))  # same paths; float64 sums in another order
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (split, diff.max(), (diff > 0).mean())
+
+
+def test_three_replicas_and_the_callers_band_split_is_refused(two_devices):
+    import ctypes as C
+    from raytrace_amd import _lib
+    lib, _ = two_devices
+    sc = scenes.charuco(dx=200, dy=150, spp=3)
+    one = _render(sc)
+    _lib.init(lib, [0, 0, 0])
+    assert np.array_equal(_render(sc, abi.SPLIT_ROWS).Image, one.Image)
+    with phys.DeviceScene(sc) as dev:
+        img = np.zeros((150, 200, 4), dtype=np.uint8)
+        cd = phys.camera_desc(sc.Camera[0])
+        ro = phys.render_opts(sc.RenderOptions, band_rank=0, band_world=2)
+        rc = lib.rt_render(dev.handle, C.byref(cd), C.byref(ro), img.ctypes.data_as(C.POINTER(C.c_uint8)), 800, None)
+        assert rc == abi.RT_ERR_INVALID and b"several devices" in lib.rt_last_error()
