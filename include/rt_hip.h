@@ -331,6 +331,24 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opt
 int rt_render_film(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts,
                    double* film_dev, rt_stats* stats);
 
+/* rt_render_film without a single device allocation, for callers that cannot
+ * allocate: code under HIP graph capture, tight frame loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference.  Same arguments, same
+ * film, same statistics as rt_render_film; the counters, the camera, the queue
+ * descriptors and the tile schedule live in a static array in device memory
+ * (2.1 MB, held by every GPU the library runs on until the process ends)
+ * instead of buffers owned by the scene.  Limits, each rejected with
+ * RT_ERR_UNSUPPORTED and a message: the scene must be one whose materials all
+ * just emit (Emitter, DebugUV, DebugNormal -- what the OBJ route produces,
+ * node.go:269-309; scattering materials need gigabytes of ray queues), it must
+ * live on one device, and the frame (this call's row bands of it) must have at
+ * most 262144 tiles of 8x8 pixels (4096 x 4096 pixels).  stats->traverse_seconds
+ * stays 0 (timing events would have to be created).  All calls on a GPU share
+ * that GPU's array: two of them overlapping on one GPU race, whatever their
+ * scenes or streams. */
+int rt_render_film_noalloc(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts,
+                           double* film_dev, rt_stats* stats);
+
 /* Quantise a summed film exactly as renderPixel does (render.go:218-224):
  * c = sum / rays_per_pixel; byte = uint8(min(255, 255.99 * c)).  rgba_out is a
  * host buffer. */

@@ -11,7 +11,7 @@ _PATH = os.environ.get("RT_LIB_PATH") or os.path.join(os.path.dirname(os.path.ab
 SYMBOLS = [
     "rt_apply_filter", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
     "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info", "rt_obj_scan_text", "rt_obj_scan_free",
-    "rt_bvh_build",
+    "rt_bvh_build", "rt_render_film_noalloc",
 ]
 
 
@@ -48,6 +48,8 @@ def open_library() -> C.CDLL:
     lib.rt_render.restype = C.c_int
     lib.rt_render_film.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), C.c_void_p, P(abi.Stats)]
     lib.rt_render_film.restype = C.c_int
+    lib.rt_render_film_noalloc.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), C.c_void_p, P(abi.Stats)]
+    lib.rt_render_film_noalloc.restype = C.c_int
     lib.rt_film_resolve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, P(C.c_uint8), C.c_size_t, C.c_void_p]
     lib.rt_film_resolve.restype = C.c_int
     lib.rt_cancel.argtypes = [C.c_void_p]

@@ -57,6 +57,18 @@ void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s);
 void launch_film_add(double* dst, const double* src, size_t n, hipStream_t s);  // dst[i] += src[i], both on the current device
 
+// Static scratch of rt_render_film_noalloc: a file-scope __device__ array in kernels.hip.  Layout (offsets in bytes, each
+// a multiple of 256): Counters, DCamera, Queues, then kStaticTiles tile costs and kStaticTiles tile numbers.
+constexpr int64_t kStaticTiles = 1 << 18;  // 8x8-pixel tiles: frames up to 4096 x 4096 pixels
+constexpr int kStaticScratchDevices = 64;
+constexpr size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+constexpr size_t kStaticOffCamera = align256(sizeof(Counters));
+constexpr size_t kStaticOffQueues = kStaticOffCamera + align256(sizeof(DCamera));
+constexpr size_t kStaticOffCost = kStaticOffQueues + align256(sizeof(Queues));
+constexpr size_t kStaticOffOrder = kStaticOffCost + (size_t)kStaticTiles * sizeof(uint32_t);
+constexpr size_t kStaticScratchBytes = kStaticOffOrder + (size_t)kStaticTiles * sizeof(int32_t);
+// Address of that array on `device` (looked up once per device with that device current, then kept).
+hipError_t static_scratch(int device, void** ptr);
 // src and dst: packed dx*dy RGBA8 device images; tmp: dx*dy*3 float64
 #ifdef RT_VISIT_STATS
 void debug_packet_stats(unsigned long long* out8, bool reset);  // diagnostics build only

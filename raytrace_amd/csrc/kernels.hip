@@ -993,6 +993,39 @@ void launch_film_add(double* dst, const double* src, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_film_add, dim3(blocks_for(n)), dim3(kBlock), 0, s, dst, src, n);
 }
 
+// ---- static scratch ------------------------------------------------------------------------------
+// Device memory the library owns without ever allocating it: every GPU that loads this code object holds its own
+// copy of the array, at its own address, until the process ends.  rt_render_film_noalloc keeps its counters, camera,
+// queue descriptors and tile schedule here.  In host code the array's name is only a handle for
+// hipGetSymbolAddress; what kernels, memsets and copies receive is the address that call returns on the device
+// in question.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kStaticScratchDevices] = {};  // per device ordinal; null = not looked up yet
+}  // namespace
+
+hipError_t static_scratch(int device, void** ptr) {
+    *ptr = nullptr;
+    if (device < 0 || device >= kStaticScratchDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        int before = 0;
+        hipError_t e = hipGetDevice(&before);
+        if (e != hipSuccess) return e;
+        e = hipSetDevice(device);  // the symbol resolves to the copy of the CURRENT device
+        if (e != hipSuccess) return e;
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        (void)hipSetDevice(before);
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *ptr = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s) {
     const int32_t n = dx * dy;
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for((uint64_t)n)), dim3(kBlock), 0, s, film, n, spp, reinterpret_cast<uchar4*>(rgba));

@@ -358,6 +358,41 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& ge
 
 }  // namespace
 
+// The static scratch of every device dressed up as WorkBuffers.  Only scenes whose materials all just emit render from
+// it (they queue nothing), so the queue views stay empty; the schedule arrays are the scratch's own.
+WorkBuffers* static_work_for(int device, int64_t tiles_total) {
+    static WorkBuffers table[kStaticScratchDevices];
+    if (device < 0 || device >= kStaticScratchDevices) {
+        fail(RT_ERR_UNSUPPORTED, "device ordinal beyond the static scratch table");
+        return nullptr;
+    }
+    if (tiles_total > kStaticTiles) {
+        fail(RT_ERR_UNSUPPORTED, "frame too large for the static scratch: " + std::to_string(tiles_total) + " tiles of 8x8 pixels, at most " +
+                                     std::to_string(kStaticTiles) + " (4096 x 4096 pixels)");
+        return nullptr;
+    }
+    WorkBuffers& w = table[device];
+    if (!w.is_static) {
+        void* base = nullptr;
+        const hipError_t e = static_scratch(device, &base);
+        if (e != hipSuccess) {
+            fail(RT_ERR_DEVICE, std::string("static scratch: ") + hipGetErrorString(e));
+            return nullptr;
+        }
+        char* p = static_cast<char*>(base);
+        w.q = 64 * 64;
+        w.primary_waves = 64;
+        w.queues.counters = reinterpret_cast<Counters*>(p);
+        w.d_camera = reinterpret_cast<DCamera*>(p + kStaticOffCamera);
+        w.d_queues = reinterpret_cast<Queues*>(p + kStaticOffQueues);
+        w.tile_cost = reinterpret_cast<uint32_t*>(p + kStaticOffCost);
+        w.tile_order = reinterpret_cast<int32_t*>(p + kStaticOffOrder);
+        w.order_tiles = (size_t)kStaticTiles;
+        w.is_static = true;
+    }
+    return &w;
+}
+
 int scene_film(const rt_scene* sc, Replica& rep, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host) {
     if (int rc = ensure_work(sc, rep)) return rc;
     WorkBuffers& w = *rep.work;

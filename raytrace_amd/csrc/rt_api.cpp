@@ -179,6 +179,10 @@ int rt_init(const int* gpu_ids, int n) {
     }
     for (int dev : devices) {
         HIP_TRY(hipSetDevice(dev));
+        // the static scratch of rt_render_film_noalloc: its address on this device is looked up now, so that the
+        // entry point itself only reads it (the look-up may load the code object, which allocates)
+        void* scratch_ptr = nullptr;
+        HIP_TRY(static_scratch(dev, &scratch_ptr));
         for (int other : devices) {  // films travel between the devices: direct access where the links allow it
             int can = 0;
             if (other == dev || hipDeviceCanAccessPeer(&can, dev, other) != hipSuccess || !can) continue;
@@ -530,6 +534,23 @@ void rt_cancel(rt_scene* scene) {
 int rt_render_film(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* film_dev, rt_stats* stats) {
     if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
     return render_all_devices(scene, camera, opts, film_dev, stats);
+}
+
+int rt_render_film_noalloc(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* film_dev, rt_stats* stats) {
+    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    if (!scene || !camera || !opts || !film_dev) return fail(RT_ERR_INVALID, "null argument");
+    if (scene->replicas.size() != 1) return fail(RT_ERR_UNSUPPORTED, "rt_render_film_noalloc renders scenes that live on one device");
+    if (opts->dx <= 0 || opts->dy <= 0) return fail(RT_ERR_INVALID, "bad Dx / Dy must be positive");
+    // this call's rows (its bands of 16) in whole groups of 64 x 64 pixels, as the render loop counts its tiles
+    const int world = opts->band_world > 0 ? opts->band_world : 1;
+    int64_t local_rows = 0;
+    for (int r = 0; r < opts->dy; r++)
+        if ((r / 16) % world == opts->band_rank) local_rows++;
+    const int64_t tiles = (int64_t)((opts->dx + 63) / 64) * ((local_rows + 63) / 64) * 64;
+    Replica& rep = *scene->replicas[0];
+    WorkBuffers* w = static_work_for(rep.device, tiles);
+    if (!w) return RT_ERR_UNSUPPORTED;  // message set by static_work_for
+    return render_into_film(scene, rep, camera, opts, film_dev, stats, w);
 }
 
 int rt_film_resolve(const double* film_dev, int32_t dx, int32_t dy, int32_t rays_per_pixel, uint8_t* rgba_out, size_t stride, void* stream_) {
