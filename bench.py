@@ -10,7 +10,13 @@ into 16-row bands dealt round-robin to the ranks, every rank keeps the whole sce
 HBM, and the per-rank films are gathered onto rank 0 with one RCCL gather after the last step.
 
 Prints ONE JSON line on rank 0.  `value` is TotalRays (the reference's RenderStats counter,
-render.go:143) of all ranks divided by the slowest rank's wall time for the K timed steps.
+render.go:143) of all ranks divided by the slowest rank's wall time for the K timed steps, with
+EVERY tile of the frame traced on the GPU: the library's shortcut for tiles that cannot see the
+scene (it counts their rays on the host without generating them) is switched off for the timed
+steps, so that every ray in `value` is a ray a kernel generated and traced, as every ray of the
+CPU baseline is.  The same steps with the shortcut on (the library's default) are run afterwards
+and reported as `config.value_with_culling` (reference-counted rays per second, i.e. the frame
+rate a caller sees) and `config.value_traced_rays` (only the rays a kernel traced, per second).
 """
 import argparse
 import ctypes as C
@@ -37,7 +43,9 @@ def parse():
     p.add_argument("--spp", type=int, default=1024, help="RaysPerPixel of the configuration")
     p.add_argument("--tex", type=int, default=4096)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-all-tiles-leg", action="store_true", help="skip the extra, unmeasured steps with the screen-bounds culling off")
+    p.add_argument("--no-culling-leg", action="store_true", help="skip the extra, untimed steps with the screen-bounds culling on")
+    p.add_argument("--no-cold-frame", action="store_true", help="skip the cold-frame measurement on a fresh scene handle")
+    p.add_argument("--culling", action="store_true", help="run the TIMED steps with the culling on (profiling aid; `value` then counts host-settled rays)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the baseline sample")
     p.add_argument("--emulate-world", type=int, default=0,
                    help="single process renders only the row bands that rank 0 of this many ranks would own (scaling rehearsal)")
@@ -123,11 +131,16 @@ def main():
     film = torch.zeros((o.Dy, o.Dx, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step(k):
+    def step(k, culling=False):
         s0 = (k * a.spp_step) % o.RaysPerPixel
         cnt = min(a.spp_step, o.RaysPerPixel - s0)
         ro = phys.render_opts(o, abi.MODE_FAST, rank, a.emulate_world or world, stream, s0, cnt)
         st = abi.Stats()
+        # RT_NO_PIXEL_CULL is read by the library at every call: set = every tile is traced
+        if culling:
+            os.environ.pop("RT_NO_PIXEL_CULL", None)
+        else:
+            os.environ["RT_NO_PIXEL_CULL"] = "1"
         _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
         return st
 
@@ -137,40 +150,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(a.warmup):
-        step(k)
-    if a.warmup > 0:
-        # the first gather of a process group sets up its point-to-point connections (the barrier's all-reduce
-        # does not): that one-off cost belongs to the warm-up, like the first launch of a kernel
-        shard.combine_films(film)
-    film.zero_()
-    fence()
-    t_begin = time.perf_counter()
-    rays = trav_s = 0.0
-    trav_launches = trav_rays = culled = 0
-    for k in range(a.steps):
-        st = step(k)
-        rays += st.total_rays
-        trav_s += st.traverse_seconds
-        trav_launches += st.traverse_launches
-        trav_rays += st.traverse_rays
-        culled += st.culled_rays
-    shard.combine_films(film)  # the per-GPU films hold disjoint row bands: one sum onto rank 0 assembles the frame
-    fence()
-    elapsed = time.perf_counter() - t_begin
-    tot = torch.tensor([rays, elapsed, trav_s, float(trav_launches), float(trav_rays), float(culled)], dtype=torch.float64, device="cuda")
-    tot, mx = shard.combine_counters(tot)
-    elapsed = float(mx[1])  # the slowest rank's wall time
-    rays_all = float(tot[0])
+    def leg(culling, steps, warmup, combine):
+        """`warmup` untimed steps, then `steps` timed ones between two fences.  Returns the whole-job totals
+        (sums over ranks) and the slowest rank's wall time."""
+        for k in range(warmup):
+            step(k, culling)
+        if combine and warmup > 0:
+            # the first gather of a process group sets up its point-to-point connections (the barrier's all-reduce
+            # does not): that one-off cost belongs to the warm-up, like the first launch of a kernel
+            shard.combine_films(film)
+        film.zero_()
+        fence()
+        t_begin = time.perf_counter()
+        acc = dict(rays=0.0, trav_s=0.0, launches=0.0, trav_rays=0.0, culled=0.0)
+        for k in range(steps):
+            st = step(k, culling)
+            acc["rays"] += st.total_rays
+            acc["trav_s"] += st.traverse_seconds
+            acc["launches"] += st.traverse_launches
+            acc["trav_rays"] += st.traverse_rays
+            acc["culled"] += st.culled_rays
+        if combine:
+            shard.combine_films(film)  # the per-GPU films hold disjoint row bands: one sum onto rank 0 assembles the frame
+        fence()
+        elapsed = time.perf_counter() - t_begin
+        mine = dict(acc)
+        tot = torch.tensor([acc["rays"], elapsed, acc["trav_s"], acc["launches"], acc["trav_rays"], acc["culled"]], dtype=torch.float64, device="cuda")
+        tot, mx = shard.combine_counters(tot)
+        return dict(rays=float(tot[0]), elapsed=float(mx[1]), trav_rays=float(tot[4]), culled=float(tot[5]), mine=mine)
+
+    main_leg = leg(a.culling, a.steps, a.warmup, True)
+    elapsed = main_leg["elapsed"]  # the slowest rank's wall time
+    rays_all = main_leg["rays"]
+    trav_s, trav_launches, trav_rays = main_leg["mine"]["trav_s"], main_leg["mine"]["launches"], main_leg["mine"]["trav_rays"]
+    out_img = None
+    spp_done = min(a.steps * a.spp_step, o.RaysPerPixel)
+    if rank == 0:
+        out_img = np.zeros((o.Dy, o.Dx, 4), dtype=np.uint8)
+        _lib.check(lib.rt_film_resolve(C.c_void_p(film.data_ptr()), o.Dx, o.Dy, max(spp_done, 1),
+                                       out_img.ctypes.data_as(C.POINTER(C.c_uint8)), o.Dx * 4, None), lib)
+    film_main = film.clone() if (a.check and rank == 0) else None
+    cull_leg = None
+    if not a.no_culling_leg and not a.culling:
+        # The same steps with the library's default schedule (tiles that cannot see the scene are settled by the host),
+        # outside the timed region.  One warm-up step: it holds the pilot pass and the occupancy map.
+        cull_leg = leg(True, a.steps, 1, False)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    out_img = np.zeros((o.Dy, o.Dx, 4), dtype=np.uint8)
-    spp_done = min(a.steps * a.spp_step, o.RaysPerPixel)
-    _lib.check(lib.rt_film_resolve(C.c_void_p(film.data_ptr()), o.Dx, o.Dy, max(spp_done, 1),
-                                   out_img.ctypes.data_as(C.POINTER(C.c_uint8)), o.Dx * 4, None), lib)
     value = rays_all / elapsed / 1e6
     result = {
         "metric": "Mrays/sec (whole node), einstein-scan mesh 4K",
@@ -191,46 +220,69 @@ def main():
                         f"MaxRayDepth {o.MaxRayDepth}; one step = {a.spp_step} sample indices of every pixel",
             "mode": "fast (float32 conservative box culling, float64 face intersection)",
             "parallelism": f"16-row bands round-robin over {world} GPU(s), scene replicated, one RCCL gather of each GPU's rows",
+            "timed_steps": "every tile traced on the GPU (RT_NO_PIXEL_CULL=1): value counts only rays a kernel generated and traced"
+                           if not a.culling else "library default: tiles that cannot see the scene are settled by the host",
             "bvh_nodes": int(info.n_nodes), "bvh_depth": int(info.max_depth), "bvh_build_s": info.build_seconds,
             "scene_upload_s": upload_s,
             "rays_per_step_all_gpus": rays_all / max(a.steps, 1),
             "rank0_kernel_ms_per_step": 1e3 * float(trav_s) / max(a.steps, 1),
-            # camera rays of 8x8 tiles that lie outside the screen bounds of the scene: counted like the reference counts
-            # them (TotalRays, RaysLeftScene), settled without being generated (RT_NO_PIXEL_CULL=1 traces them)
-            "culled_ray_fraction": float(tot[5]) / max(rays_all, 1.0),
+            "culled_ray_fraction_timed_steps": main_leg["culled"] / max(rays_all, 1.0),
         },
     }
+    if cull_leg is not None:
+        # camera rays of 8x8 tiles that lie outside the screen outline of the scene: counted like the reference counts
+        # them (TotalRays, RaysLeftScene), settled without being generated
+        result["config"]["value_with_culling"] = cull_leg["rays"] / cull_leg["elapsed"] / 1e6
+        result["config"]["value_traced_rays"] = cull_leg["trav_rays"] / cull_leg["elapsed"] / 1e6
+        result["config"]["ms_per_step_with_culling"] = 1e3 * cull_leg["elapsed"] / max(a.steps, 1)
+        result["config"]["culled_ray_fraction"] = cull_leg["culled"] / max(cull_leg["rays"], 1.0)
     base = None
     if not a.no_cpu_baseline:
         base = cpu_baseline(scene, o, a.cpu_seconds)
         result["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
     # Roofline of the dominant kernel, k_primary<fast, mesh-only> (camera ray + closest-hit traversal + emitter
-    # shading, one launch per step), over rank 0's launches.  Algorithmic bytes of a ray =
+    # shading, one launch per step), over rank 0's launches of the timed steps.  Algorithmic bytes of a ray =
     #   32 (ray in) + 32 * boxes tested + 48 * faces tested + 16 (hit out)     traversal, reference visit order
     #   + 16 (film accumulate per sample) + 16 * P(hit) (4 RGBA8 texels per shaded hit)
     # with the box / face counts of the REFERENCE-order traversal measured by the CPU oracle on its sample of
     # the same frame; the launch time is the library's HIP-event time around the launches on their stream.
+    # `traffic`, `hbm_counter_frac` and the `roofline_valu` block come from hardware counters, which cannot be read
+    # inside this process: they are STORED values of the rocprofv3 passes over this same command
+    # (tools/profile_pmc.sh -> tools/make_counters.py -> profiles/counters.json), not measured in this run.
+    stored = None
+    cpath = os.path.join(ROOT, "profiles", "counters.json")
+    if os.path.exists(cpath):
+        with open(cpath) as f:
+            stored = json.load(f)
     if base is not None and trav_launches > 0:
         hit_fraction = 1.0 - base["miss_fraction"]
         bytes_per_ray = 32.0 + 32.0 * base["boxes_per_ray"] + 48.0 * base["faces_per_ray"] + 16.0 + 16.0 + 16.0 * hit_fraction
         my_rays = float(trav_rays)
         my_secs = float(trav_s)
         achieved = bytes_per_ray * my_rays / max(my_secs, 1e-12) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("k_primary_hbm_bytes_per_launch")
+        avg_launch_s = my_secs / max(float(trav_launches), 1.0)
+        traffic = stored.get("k_primary_hbm_bytes_per_launch") if stored else None
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": "stored profile value (profiles/counters.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command), not measured in this run",
+            "hbm_counter_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "kernel": "k_primary<fast, mesh-only>", "bytes_per_ray": bytes_per_ray, "boxes_per_ray": base["boxes_per_ray"],
             "faces_per_ray": base["faces_per_ray"], "rays_per_launch": my_rays / max(float(trav_launches), 1.0),
-            "avg_launch_ms": 1e3 * my_secs / max(float(trav_launches), 1.0), "miss_fraction": base["miss_fraction"],
-            "note": "algorithmic bytes use the reference's left-first visit counts; the scene (about 250 MB) is served from L2 and "
-                    "the 256 MB memory-side cache, so measured HBM traffic is far below them and frac can exceed 1: the kernel is "
-                    "bound by VALU issue and load latency, not by HBM",
+            "avg_launch_ms": 1e3 * avg_launch_s, "miss_fraction": base["miss_fraction"],
+            "note": "algorithmic bytes price every box and face test of the reference's left-first walk as an HBM access; the kernel "
+                    "walks a mesh once per 64 rays (wave packet, nodes through the scalar cache) and the scene (about 340 MB) sits in "
+                    "L2 and the 256 MB memory-side cache, so frac exceeds 1 and says nothing about HBM: hbm_counter_frac is the "
+                    "measured HBM share, and the bound that limits the kernel is vector instruction issue (roofline_valu)",
         }
+        if stored and "k_primary_valu_busy" in stored:
+            result["roofline_valu"] = {
+                "bound": "valu", "achieved": stored["k_primary_valu_busy"], "peak": 1.0, "unit": "fraction of SIMD issue cycles",
+                "frac": stored["k_primary_valu_busy"],
+                "lanes_enabled": stored.get("k_primary_lanes_enabled"),
+                "valu_insts_per_traced_ray": stored.get("k_primary_valu_insts_per_ray"),
+                "source": "stored profile value (profiles/counters.json): 4 x SQ_ACTIVE_INST_VALU / (SIMDs x kernel cycles) of the timed launches of this command under rocprofv3 --pmc",
+            }
     if a.check:  # radiance sums of the timed steps against the CPU oracle, on every 16th tile row and column
         from oracle import binding as ob
         with ob.OracleScene(scene) as orc:
@@ -239,26 +291,24 @@ def main():
             ref_film = np.zeros((o.Dy, o.Dx, 3), dtype=np.float64)
             ref, _, _, _ = _oracle_render(orc, scene, probe, ro, 16, 16, ref_film)
         mask = ref[..., 3] == 255
-        got = film.cpu().numpy()[mask]
+        got = film_main.cpu().numpy()[mask]
         want = ref_film[mask]
         err = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
         result["check"] = {"pixels": int(mask.sum()), "samples_per_pixel": int(spp_done), "max_rel_diff_of_sums": float(err.max()),
                            "frac_rel_diff_gt_1e-9": float((err > 1e-9).mean()), "nonzero_fraction": float((want > 0).any(axis=1).mean())}
-    if world == 1 and result["config"]["culled_ray_fraction"] > 0 and not a.emulate_world and not a.no_all_tiles_leg:
-        # The same steps once more with every tile traced (no screen-bounds culling), outside the measured region:
-        # how much of `value` the culling accounts for.  The film is scratch by now.
-        os.environ["RT_NO_PIXEL_CULL"] = "1"
-        try:
-            step(0)  # new schedule (pilot pass)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            rays2 = 0
-            for k in range(a.steps):
-                rays2 += step(k).total_rays
-            torch.cuda.synchronize()
-            result["config"]["value_all_tiles_traced"] = rays2 / (time.perf_counter() - t0) / 1e6
-        finally:
-            del os.environ["RT_NO_PIXEL_CULL"]
+    if world == 1 and not a.emulate_world and not a.no_cold_frame:
+        # One whole frame on a FRESH scene handle through rt_render, as a caller that renders a single frame gets it:
+        # pilot pass, occupancy map and schedule, every pass of the frame, quantisation and the copy to the host.
+        os.environ.pop("RT_NO_PIXEL_CULL", None)
+        t0 = time.perf_counter()
+        dev2 = phys.DeviceScene(scene)
+        t1 = time.perf_counter()
+        art = dev2.render(scene.Camera[0], o, abi.MODE_FAST)
+        t2 = time.perf_counter()
+        dev2.close()
+        result["config"]["cold_frame_s"] = t2 - t1
+        result["config"]["cold_frame_with_scene_create_s"] = t2 - t0
+        result["config"]["cold_frame_rays"] = int(art.Stats.TotalRays)
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

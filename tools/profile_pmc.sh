@@ -5,7 +5,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/pmc"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="${PMC_ARGS:---no-cpu-baseline --no-all-tiles-leg}"   # default: the launches of a default bench.py run
+ARGS="${PMC_ARGS:---no-cpu-baseline --no-culling-leg --no-cold-frame}"   # default: the launches of a default bench.py run
 ONLY="$*"   # optional list of pass names; default all
 run() {
   name=$1; shift
