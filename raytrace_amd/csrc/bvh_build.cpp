@@ -315,6 +315,43 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
         out.fast_nodes[0] = f;
     }
 
+    // The quantised copy of the tree.  The grid spans the union of all child boxes (they carry the padding), widened a little.
+    {
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        bool any = false;
+        for (const FastNode& f : out.fast_nodes)
+            for (int k = 0; k < 2; k++) {
+                if (f.child[k] == kFastEmpty) continue;
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = any ? std::min(lo[a], f.b[k][a][0]) : f.b[k][a][0];
+                    hi[a] = any ? std::max(hi[a], f.b[k][a][1]) : f.b[k][a][1];
+                }
+                any = true;
+            }
+        for (int a = 0; a < 3; a++) {
+            const float ext = std::max(hi[a] - lo[a], 1e-30f);
+            out.grid_lo[a] = lo[a] - 4.0f * ext / 65535.0f;
+            out.grid_step[a] = round_up((double)(hi[a] + 4.0f * ext / 65535.0f - out.grid_lo[a]) / 65520.0);  // every plane lands inside [8, 65528)
+        }
+        out.q_nodes.resize(out.fast_nodes.size());
+        for (size_t i = 0; i < out.fast_nodes.size(); i++) {
+            const FastNode& f = out.fast_nodes[i];
+            QNode& qn = out.q_nodes[i];
+            for (int k = 0; k < 2; k++) {
+                qn.child[k] = f.child[k];
+                for (int a = 0; a < 3; a++) {
+                    if (f.child[k] == kFastEmpty) { qn.q[k][a][0] = 65535; qn.q[k][a][1] = 0; continue; }
+                    // float64 here: the division is exact enough that one extra step on each side covers its rounding and
+                    // that of the device's float32 plane * step + offset
+                    const double pmin = ((double)f.b[k][a][0] - (double)out.grid_lo[a]) / (double)out.grid_step[a];
+                    const double pmax = ((double)f.b[k][a][1] - (double)out.grid_lo[a]) / (double)out.grid_step[a];
+                    qn.q[k][a][0] = (uint16_t)std::max(0.0, std::floor(pmin) - 1.0);
+                    qn.q[k][a][1] = (uint16_t)std::min(65535.0, std::ceil(pmax) + 1.0);
+                }
+            }
+        }
+    }
+
     out.fast_depth = std::max(fl.fast_depth, 1);
     out.prim_face.resize(n_faces);
     out.prim_pos.resize(n_faces * 9);

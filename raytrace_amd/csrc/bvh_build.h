@@ -34,6 +34,18 @@ struct FastNode {
 };
 static_assert(sizeof(FastNode) == 64, "FastNode layout");
 
+// The same node for walks that fetch it per lane (scattered and shadow rays: every lane of a wave stands on a different
+// node, and what bounds those walks is the number of 16-byte requests the lanes send to the L1, not arithmetic): the
+// twelve planes as 16-bit positions on a grid laid over the mesh's padded bounds, 32 bytes instead of 64.  Plane p of
+// axis a lies at grid_lo[a] + p * grid_step[a] in the mesh frame; mins are rounded down and maxes up and both moved one
+// more step outward, so a quantised box contains the float32 box of the FastNode with the same index and child
+// references.  An empty slot keeps child == kFastEmpty.
+struct QNode {
+    uint16_t q[2][3][2];  // [child][axis][0 = min, 1 = max]
+    int32_t child[2];
+};
+static_assert(sizeof(QNode) == 32, "QNode layout");
+
 // Float32 copy of a face for the conservative pre-test that runs before the float64
 // intersection: p0 relative to the mesh centre, the two edges, and their lengths (the
 // error bound of the pre-test scales with them).  48 bytes.
@@ -49,6 +61,8 @@ static_assert(sizeof(Tri32) == 48, "Tri32 layout");
 struct MeshBvh {
     std::vector<RefNode> ref_nodes;
     std::vector<FastNode> fast_nodes;
+    std::vector<QNode> q_nodes;       // index for index the same tree as fast_nodes
+    float grid_lo[3], grid_step[3];   // the grid of q_nodes, mesh frame
     std::vector<int32_t> prim_face;   // leaf order -> face index inside the mesh
     std::vector<double> prim_pos;     // leaf order, 9 float64 per face (P0, P1, P2)
     std::vector<Tri32> prim_tri32;    // leaf order

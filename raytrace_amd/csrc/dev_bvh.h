@@ -7,7 +7,33 @@ namespace rt {
 
 struct VisitCounts {
     uint32_t boxes, prims;
+    // Set when a traversal stack ran full (the host sizes them so that it cannot happen).  Kept in a register and turned
+    // into one atomic at the very end of a kernel: an atomic inside the walk would make every load after it "possibly
+    // clobbered", and the compiler then gives up the scalar loads of wave-uniform scene data.
+    bool overflow = false;
+#ifdef RT_VISIT_STATS
+    // per-lane walk, diagnostics: [0] walks of the wave, [1] lanes in them, [2] inner-node steps of the wave, [3] lanes in
+    // them, [4] face steps, [5] lanes in them; [6..11] the same for any-hit walks (all wave-uniform sums)
+    uint32_t w[12] = {};
+#endif
 };
+
+// Diagnostics (builds with -DRT_VISIT_STATS only): events per wave, summed over the launch.
+#ifdef RT_VISIT_STATS
+__device__ unsigned long long g_packet_stats[16];  // packet walk: walks, inner nodes, leaves, float32 face tests, float64 face tests, pops, pushes, -, cycles in walks, cycles in rounds, rounds, cycles in leaves
+__device__ unsigned long long g_trace_stats[64][64];   // k_trace / k_direct, striped by workgroup; see render.cpp's print-out
+#define RT_STAT(i, n) do { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&g_packet_stats[i], (unsigned long long)(n)); } while (0)
+#define RT_TSTAT(i, n) do { const unsigned long long v_ = (unsigned long long)(n); if ((threadIdx.x & 63) == 0) atomicAdd(&g_trace_stats[(blockIdx.x + blockIdx.y * 7u) & 63u][i], v_); } while (0)
+#define RT_WSTAT(i, n) do { cnt.w[(ANY_HIT ? 6 : 0) + (i)] += (uint32_t)(n); } while (0)
+#define RT_FIRST_ACTIVE (((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) ? 1 : 0)
+// every lane adds its own tallies (first-active-lane tallies add up to the wave's step counts)
+#define RT_WFLUSH(c) do { for (int k_ = 0; k_ < 12; k_++) if ((c).w[k_]) atomicAdd(&g_trace_stats[(blockIdx.x + threadIdx.x) & 63u][16 + k_], (unsigned long long)(c).w[k_]); } while (0)
+#else
+#define RT_STAT(i, n) do { } while (0)
+#define RT_TSTAT(i, n) do { } while (0)
+#define RT_WSTAT(i, n) do { } while (0)
+#define RT_WFLUSH(c) do { } while (0)
+#endif
 
 // AABB.hit, shape.go:81-96: per axis 1/d, swap on negative, Go's NaN-propagating Max/Min,
 // reject when tmax <= tmin.
@@ -61,7 +87,8 @@ RT_DEV bool mesh_collide_ref(const DScene& sc, const DMesh& m, const Ray& r, dou
                     }
                 }
             } else {
-                if (sp < 40) stack[sp++] = n->right;
+                if (sp < 40) stack[sp++] = n->right;  // NewBVH stops at depth 32 (shape_bvh.go:104): 33 entries at most
+                else cnt.overflow = true;
                 cur = cur + 1;
                 descend = true;
             }
@@ -138,29 +165,6 @@ RT_DEV float up32(double x) {  // float32 not below x
     return f;
 }
 
-// Traversal stack of (child reference, entry distance) pairs, entirely in LDS: this lane's
-// column of a [2 * pairs][lanes] array (dword i at lds[i * stride]).  Near-first descent pushes at
-// most one pair per tree level, so the host sizes the array from the depth of the deepest fast tree
-// of the scene and the stack cannot overflow; nothing goes to private (scratch) memory.
-struct PairStack {
-    int32_t* lds;
-    int stride;
-    int cap;  // pairs available
-    int sp;
-    RT_DEV void push(int32_t ref, float t) {
-        if (sp < cap) {
-            lds[(2 * sp) * stride] = ref;
-            lds[(2 * sp + 1) * stride] = __float_as_int(t);
-            sp++;
-        }
-    }
-    RT_DEV void pop(int32_t& ref, float& t) {
-        sp--;
-        ref = lds[(2 * sp) * stride];
-        t = __int_as_float(lds[(2 * sp + 1) * stride]);
-    }
-};
-
 // A node read through the constant address space: with a wave-uniform index the compiler emits scalar loads
 // (s_load_dwordx4 into SGPRs, served by the scalar data cache) instead of per-lane vector loads.
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
@@ -212,6 +216,33 @@ RT_DEV bool tri32_rejects(const Tri32& t, const FastRay& f, float dx, float dy, 
     return us < -eu || vs < -ev || us + vs > aa + eu + ev + ea;
 }
 
+// Traversal stack of (child reference, entry distance) pairs, entirely in LDS: this lane's
+// column of a [2 * pairs][lanes] array (dword i at lds[i * stride]).  Near-first descent pushes at
+// most one pair per tree level, so the host sizes the array from the depth of the deepest fast tree
+// of the scene and the stack cannot overflow; nothing goes to private (scratch) memory.  A push that
+// finds it full all the same sets `overflow` (the host turns that into a failed render).
+struct PairStack {
+    int32_t* lds;
+    int stride;
+    int cap;  // pairs available
+    int sp;
+    bool overflow;
+    RT_DEV void push(int32_t ref, float t) {
+        if (sp < cap) {
+            lds[(2 * sp) * stride] = ref;
+            lds[(2 * sp + 1) * stride] = __float_as_int(t);
+            sp++;
+        } else {
+            overflow = true;
+        }
+    }
+    RT_DEV void pop(int32_t& ref, float& t) {
+        sp--;
+        ref = lds[(2 * sp) * stride];
+        t = __int_as_float(lds[(2 * sp + 1) * stride]);
+    }
+};
+
 // Closest (or any) hit of one mesh.  while-while form: every lane first walks inner nodes until it
 // holds a leaf (or runs out of work), then the lanes of the wave test their leaves together, so the
 // float64 intersections run with most lanes active instead of stalling the node loop.
@@ -233,11 +264,16 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
     st.stride = stride;
     st.cap = cap;
     st.sp = 0;
+    st.overflow = false;
     constexpr int32_t kDone = kFastEmpty;
     int32_t cur = 0;
     bool hit = false;
+    RT_WSTAT(0, RT_FIRST_ACTIVE);
+    RT_WSTAT(1, 1);
     for (;;) {
         while (cur >= 0) {  // inner node: test both children, go to the nearer, push the farther
+            RT_WSTAT(2, RT_FIRST_ACTIVE);
+            RT_WSTAT(3, 1);
             // When every active lane stands on the same node (the usual case when the lanes of a wave trace samples of
             // one pixel) the node is fetched once through the scalar cache into SGPRs instead of 64 times through the
             // vector memory pipeline, whose return path (64 B per clock per CU) is what bounds this loop otherwise.
@@ -291,13 +327,15 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
             const int32_t count = (int32_t)(code & 7u) + 1;
             for (int32_t q = 0; q < count; q++) {
                 cnt.prims++;
+                RT_WSTAT(4, RT_FIRST_ACTIVE);
+                RT_WSTAT(5, 1);
                 const Tri32 t32 = uniform ? load_tri32_scalar(tri32, first + q) : tri32[first + q];
                 if (tri32_rejects(t32, f, dx, dy, dz, err_r, err_d)) continue;
                 const double* p = pos + (int64_t)(first + q) * 9;
                 const V3 p0 = ld3(p), p1 = ld3(p + 3), p2 = ld3(p + 6);
                 double t, u, v;
                 if (mt_core(r, p0, p1, p2, 1e-8, tmin, tmax, t, u, v)) {
-                    if (ANY_HIT) return true;
+                    if (ANY_HIT) { cnt.overflow |= st.overflow; return true; }
                     if (hit && t == t_out && first + q < prim) continue;  // equal distances: see mesh_collide_packet
                     hit = true;
                     tmax = t;
@@ -315,7 +353,175 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
             if (tnear <= tmax32) { cur = ref; break; }
         }
     }
+    cnt.overflow |= st.overflow;
     return hit;
+}
+
+// ---- resumable per-lane walk -------------------------------------------------------------------
+//
+// The same search as mesh_collide_fast, cut into rounds so that a wave can hand finished lanes a new ray while the
+// others keep walking (k_walk): everything a lane needs between rounds lives in WalkLane and in its LDS stack.  The
+// rays of a wave are unrelated here, so nodes and faces are always fetched per lane.
+
+// The closest hit found so far over all nodes of the scene.  Among hits at exactly the same distance the lower node
+// wins (tracePath keeps the first node: `c.t < minDist`, render.go:161) and, inside a mesh, the face latest in leaf
+// order (see mesh_collide_packet), whatever order the nodes and faces were visited in.
+struct BestHit {
+    double t;
+    int32_t node;  // -1: nothing hit yet
+    int32_t leaf;  // mesh: position of the face in leaf order; other shapes: -1
+    RT_DEV bool takes(double t_new, int32_t node_new, int32_t leaf_new) const {
+        if (node < 0 || t_new < t) return true;
+        if (t_new > t) return false;
+        return node_new < node || (node_new == node && leaf_new > leaf);
+    }
+};
+
+struct WalkLane {
+    Ray lr;                          // the ray in the frame of the mesh being walked
+    float ox, oy, oz;                // its float32 origin: o + d * t_shift, relative to the mesh centre
+    double t_shift;
+    // slab distance of grid plane p of axis a: p * ga + gb (ga = grid step / direction, gb = (grid origin - ray origin) / direction)
+    float gax, gay, gaz, gbx, gby, gbz;
+    float tmin32, tmax32;
+    float dx, dy, dz, err_d, err_r;  // float32 direction and the error scales of the face pre-test
+    uint32_t node_base, prim_base;   // first FastNode / first prim (leaf order) of that mesh
+    int32_t cur;                     // >= 0: inner node; kFastEmpty: not walking; any other negative value: a leaf
+    int32_t sp;                      // entries on the stack
+    int32_t base;                    // entries [base, sp) are in the LDS ring, [0, base) in the spill area
+#ifdef RT_VISIT_STATS
+    uint32_t steps = 0;              // inner nodes visited for the current ray (diagnostics)
+#endif
+};
+
+// The stack of a resumable walk: its top kWalkRing entries in an LDS ring (entry i in slot i % kWalkRing of this lane's
+// column), older ones in a per-lane spill area in device memory.  A 22-level tree would otherwise need 23 entries per
+// lane in LDS, which caps the kernel at 3 waves per SIMD; most pushes and pops never leave the ring.
+#ifndef RT_WALK_RING
+#define RT_WALK_RING 8
+#endif
+constexpr int kWalkRing = RT_WALK_RING;
+static_assert((kWalkRing & (kWalkRing - 1)) == 0, "the ring index is a mask");
+struct WalkStack {
+    int32_t* lds;   // this lane's column: dword j of ring slot s at lds[(2 * s + j) * 64]
+    int2* spill;    // this lane's column of the wave's spill area: entry i at spill[i * 64]
+    int cap;        // entries the spill area holds (depth of the deepest tree + 1)
+};
+
+RT_DEV bool walk_begin(const DMesh& m, const Ray& lr, double tmin, double tmax, WalkLane& w) {
+    FastRay f;
+    if (!fast_setup(m, lr, tmin, tmax, f)) return false;
+    w.lr = lr;
+    w.ox = f.ox; w.oy = f.oy; w.oz = f.oz;
+    w.t_shift = f.t_shift;
+    w.gax = m.grid_step[0] * f.ix; w.gay = m.grid_step[1] * f.iy; w.gaz = m.grid_step[2] * f.iz;
+    w.gbx = (m.grid_lo[0] - f.ox) * f.ix; w.gby = (m.grid_lo[1] - f.oy) * f.iy; w.gbz = (m.grid_lo[2] - f.oz) * f.iz;
+    w.tmin32 = fmaxf(0.0f, (float)(tmin - f.t_shift));
+    w.tmax32 = up32(tmax - f.t_shift);
+    w.dx = (float)lr.d.x; w.dy = (float)lr.d.y; w.dz = (float)lr.d.z;
+    const float dlen = sqrtf(w.dx * w.dx + w.dy * w.dy + w.dz * w.dz);
+    w.err_d = kErr * dlen;
+    w.err_r = w.err_d * m.radius;
+    w.node_base = (uint32_t)m.fast_off;
+    w.prim_base = (uint32_t)m.prim_off;
+    w.cur = 0;
+    w.sp = 0;
+    w.base = 0;
+    return true;
+}
+
+// One round for a walking lane: inner nodes down to the next leaf, that leaf's faces, then the next subtree from the
+// stack.  Leaves w.cur == kFastEmpty when the walk is over.  `node` is the scene node being walked (for the tie rule),
+// tmin the ray's lower limit; best.t is the search limit.  ANY_HIT: the first face hit ends the walk (best.node >= 0 then).
+// RING: entries the LDS part of the stack holds, a power of two (older entries go to st.spill); 0: the LDS column has
+// room for all st.cap entries and nothing is ever spilled.
+template <bool ANY_HIT, int RING>
+RT_DEV void walk_round(const DScene& sc, WalkLane& w, int32_t node, double tmin, BestHit& best, const WalkStack& st, bool& overflow) {
+    const QNode* nodes = sc.q_nodes + w.node_base;
+    const double* pos = sc.prim_pos + (size_t)w.prim_base * 9;
+    const Tri32* tri32 = sc.prim_tri32 + w.prim_base;
+    FastRay f;  // what the face pre-test reads of it
+    f.ox = w.ox; f.oy = w.oy; f.oz = w.oz;
+    auto pop_next = [&]() {
+        w.cur = kFastEmpty;
+        while (w.sp > 0) {  // skipping subtrees that begin beyond the current hit
+            w.sp--;
+            int32_t ref, tbits;
+            if (RING == 0 || w.sp >= w.base) {
+                const int slot = RING ? (w.sp & (RING - 1)) : w.sp;
+                ref = st.lds[(2 * slot) * 64];
+                tbits = st.lds[(2 * slot + 1) * 64];
+            } else {  // the ring is empty: the next entry comes back from the spill area
+                const int2 e = st.spill[(size_t)w.sp * 64];
+                ref = e.x;
+                tbits = e.y;
+                w.base = w.sp;
+            }
+            if (__int_as_float(tbits) <= w.tmax32) { w.cur = ref; break; }
+        }
+    };
+    while (w.cur >= 0) {
+#ifdef RT_VISIT_STATS
+        w.steps++;
+#endif
+        const QNode n = nodes[w.cur];
+        float tn[2];
+        bool go[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            // plane positions are whole numbers below 2^16: exact in float32; the fused multiply-add rounds once
+            const f32x2 x = __builtin_elementwise_fma(f32x2{(float)n.q[k][0][0], (float)n.q[k][0][1]}, f32x2{w.gax, w.gax}, f32x2{w.gbx, w.gbx});
+            const f32x2 y = __builtin_elementwise_fma(f32x2{(float)n.q[k][1][0], (float)n.q[k][1][1]}, f32x2{w.gay, w.gay}, f32x2{w.gby, w.gby});
+            const f32x2 z = __builtin_elementwise_fma(f32x2{(float)n.q[k][2][0], (float)n.q[k][2][1]}, f32x2{w.gaz, w.gaz}, f32x2{w.gbz, w.gbz});
+            const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), w.tmin32));
+            const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), w.tmax32));
+            tn[k] = tnear;
+            go[k] = (tnear <= tfar) && n.child[k] != kFastEmpty;
+        }
+        if (go[0] && go[1]) {
+            const bool swap = tn[1] < tn[0];
+            if (w.sp < st.cap) {
+                if (RING != 0 && w.sp - w.base == RING) {  // the ring is full: its oldest entry moves to the spill area
+                    const int old = w.base & (RING - 1);
+                    st.spill[(size_t)w.base * 64] = int2{st.lds[(2 * old) * 64], st.lds[(2 * old + 1) * 64]};
+                    w.base++;
+                }
+                const int slot = RING ? (w.sp & (RING - 1)) : w.sp;
+                st.lds[(2 * slot) * 64] = swap ? n.child[0] : n.child[1];
+                st.lds[(2 * slot + 1) * 64] = __float_as_int(swap ? tn[0] : tn[1]);
+                w.sp++;
+            } else {
+                overflow = true;  // the host sizes the stack from the deepest tree: cannot happen, but must not pass silently
+            }
+            w.cur = swap ? n.child[1] : n.child[0];
+        } else if (go[0] || go[1]) {
+            w.cur = go[0] ? n.child[0] : n.child[1];
+        } else {
+            pop_next();
+        }
+    }
+    if (w.cur == kFastEmpty) return;
+    const uint32_t code = (uint32_t)~w.cur;
+    const int32_t first = (int32_t)(code >> 3);
+    const int32_t count = (int32_t)(code & 7u) + 1;
+    for (int32_t q = 0; q < count; q++) {
+        if (tri32_rejects(tri32[first + q], f, w.dx, w.dy, w.dz, w.err_r, w.err_d)) continue;
+        const double* p = pos + (int64_t)(first + q) * 9;
+        double t, u, v;
+        if (mt_core(w.lr, ld3(p), ld3(p + 3), ld3(p + 6), 1e-8, tmin, best.t, t, u, v)) {
+            if (ANY_HIT) {
+                best.node = node;
+                w.cur = kFastEmpty;
+                return;
+            }
+            if (!best.takes(t, node, first + q)) continue;
+            best.t = t;
+            best.node = node;
+            best.leaf = first + q;
+            w.tmax32 = up32(t - w.t_shift);
+        }
+    }
+    pop_next();
 }
 
 // Two-input maximum / minimum as single instructions, without the canonicalisation of the operands that the compiler
@@ -323,14 +529,6 @@ RT_DEV bool mesh_collide_fast(const DScene& sc, const DMesh& m, const Ray& r, do
 // infinity by construction).
 RT_DEV float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RT_DEV float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-
-// Diagnostics of the packet walk (builds with -DRT_VISIT_STATS only): events per wave, summed over the launch.
-#ifdef RT_VISIT_STATS
-__device__ unsigned long long g_packet_stats[16];  // walks, inner nodes, leaves, float32 face tests, float64 face tests, pops, pushes, -, cycles in walks, cycles in rounds, rounds, cycles in leaves
-#define RT_STAT(i, n) do { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&g_packet_stats[i], (unsigned long long)(n)); } while (0)
-#else
-#define RT_STAT(i, n) do { } while (0)
-#endif
 
 // The same search for a whole wave at once: one traversal, shared by all active lanes, visits every node that the
 // ray of at least one lane can reach.  The current node, the stack depth and every branch of the walk are wave-uniform,
@@ -423,6 +621,8 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
                     refs[sp] = swap ? n.child[0] : n.child[1];  // every lane stores the same value
                     lds[sp * stride] = __float_as_int(swap ? tn[0] : tn[1]);
                     sp++;
+                } else {
+                    cnt.overflow = true;  // the host sizes the stack from the deepest tree: cannot happen, but must not pass silently
                 }
                 cur = swap ? n.child[1] : n.child[0];
                 cur_tn = swap ? tn[1] : tn[0];

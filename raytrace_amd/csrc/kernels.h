@@ -35,9 +35,14 @@ struct PassDesc {
 struct Queues {
     RayQ rays[2];   // two generations: a launch traces rays[in] and appends the scattered children to rays[out]
     SurfQ surfs;    // lit surface points of the generation being shaded
+    HitQ hits;      // closest hits of the generation being traced
     Counters* counters;
     uint32_t ray_stripe_cap, surf_stripe_cap;  // entries per stripe; stripe s of a queue is [s * cap, (s + 1) * cap)
+    uint32_t hit_stripe_cap;                   // a multiple of kClaim
+    int2* walk_spill;  // k_walk: what the LDS ring of a lane's walk stack cannot hold; wave w, entry i, lane l at [(w * stack_pairs + i) * 64 + l]
 };
+
+constexpr uint32_t kWalkWavesMax = 8192;  // persistent waves of k_walk at most (the hit queue has room for a partly filled block of each)
 
 // Entries waiting in each stripe of a queue (what the cursors said, less what the host set aside).
 struct StripeCounts {
@@ -50,7 +55,9 @@ struct RayStripeCounts {
 // cam and q point to DEVICE copies of the structs
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
                     double* film, hipStream_t s);
-// traces the first n.n[s] rays of every stripe s of rays[in] and appends their children to rays[1 - in]
+// tracePath for the first n.n[s] rays of every stripe s of rays[in]: closest hit, Material.Resolve, children appended to
+// rays[1 - in], lit surface points to q.surfs, emission to the film.  Scenes with a mesh: k_walk (closest hits into
+// q.hits, lanes refilled as their rays finish) then k_shade; scenes without: one fused launch (k_trace).
 void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, const RayStripeCounts& n, int mode, bool mesh_only, double* film,
                   hipStream_t s);
 void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf, int mode, double* film, hipStream_t s);
@@ -72,6 +79,7 @@ hipError_t static_scratch(int device, void** ptr);
 // src and dst: packed dx*dy RGBA8 device images; tmp: dx*dy*3 float64
 #ifdef RT_VISIT_STATS
 void debug_packet_stats(unsigned long long* out8, bool reset);  // diagnostics build only
+void debug_trace_stats(unsigned long long* out32, bool reset);
 #endif
 void launch_filter(const uint8_t* src, int32_t w, int32_t h, int filter, double* tmp, uint8_t* dst, hipStream_t s);
 void launch_intersect_batch(const DScene& sc, const double* o, const double* d, uint64_t n, double tmin, double tmax, int mode,

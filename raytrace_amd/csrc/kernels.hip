@@ -12,7 +12,10 @@
 //   k_resolve   film sums -> 8-bit RGBA exactly as renderPixel quantises (render.go:218-224)
 #include "kernels.h"
 
+#include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
 
 #include "dev_bvh.h"
 #include "dev_shade.h"
@@ -48,6 +51,9 @@ extern __shared__ int32_t dyn_lds[];
 #ifndef RT_TRACE_SHAPES_WAVES
 #define RT_TRACE_SHAPES_WAVES 2  // k_trace for scenes without any mesh: 256 VGPRs, nothing spilled (at 3 waves 168 VGPRs + 328 B of scratch per lane: a third slower on the sphere scenes; with a mesh in the scene the walk's latency wants the third wave)
 #endif
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 3  // k_shade
+#endif
 #ifndef RT_DIRECT_WAVES
 #define RT_DIRECT_WAVES 3  // k_direct
 #endif
@@ -63,10 +69,11 @@ struct SceneHit {
     // Mesh-only scenes leave the attributes of the winning face to finish_hit(): most hits (emitters) need the
     // texture coordinates only, not the normal (a square root and three divisions) or the hit point.
     int leaf;      // >= 0: position of the face in leaf order, attributes pending; c.u / c.v hold the barycentrics
+    int rec_leaf;  // what a hit record carries: a mesh's face by its position in leaf order (also under transforms), -1 for the other shapes
 };
 
 template <int MODE, bool PACKET>
-RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, VisitCounts& cnt,
+RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, int& leaf, VisitCounts& cnt,
                               LdsStack ls);
 
 // Shape.Collide for one top-level shape.  Transformed shapes (shape_transformed_shape.go:26-57)
@@ -77,7 +84,7 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
 template <int MODE, bool PACKET = false>
 // uv_now = false: the texture coordinates of an untransformed sphere (atan2 / acos, some hundred instructions) are left
 // at 0; the caller computes them with sphere_uv() from the normal if the hit wins and its material reads them.
-RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in, double tmin, double tmax, Col& c, int& prim,
+RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in, double tmin, double tmax, Col& c, int& prim, int& leaf,
                           VisitCounts& cnt, LdsStack ls, bool uv_now = true) {
     Ray r = r_in;
     int chain[4];
@@ -92,6 +99,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
     }
     bool hit = false;
     prim = 0;
+    leaf = -1;
     switch (kind) {
         case RT_SHAPE_SPHERE:
             hit = sphere_collide(sc.spheres[index], r, tmin, tmax, c);
@@ -100,7 +108,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
         case RT_SHAPE_QUAD: hit = quad_collide(sc.quads[index], r, tmin, tmax, c); break;
         case RT_SHAPE_CYLINDER: hit = cylinder_collide(sc.cylinders[index], r, tmin, tmax, c); break;
         case RT_SHAPE_TRIANGLE: hit = tri_collide(sc.tris[index], r, tmin, tmax, c); break;
-        case RT_SHAPE_MESH: hit = mesh_node_collide<MODE, PACKET>(sc, index, r, tmin, tmax, c, prim, cnt, ls); break;
+        case RT_SHAPE_MESH: hit = mesh_node_collide<MODE, PACKET>(sc, index, r, tmin, tmax, c, prim, leaf, cnt, ls); break;
         default: break;
     }
     if (hit) {
@@ -115,7 +123,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
 
 // Mesh.Collide for a top-level (untransformed) mesh node, attributes of the winning face included.
 template <int MODE, bool PACKET>
-RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, VisitCounts& cnt,
+RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double tmin, double tmax, Col& c, int& prim, int& leaf, VisitCounts& cnt,
                               LdsStack ls) {
     const DMesh& m = sc.meshes[index];
     double t, u, v;
@@ -127,6 +135,7 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
     if (hit) {
         const double* pos = sc.prim_pos + (m.prim_off + p) * 9;
         prim = sc.prim_face[m.prim_off + p];
+        leaf = p;
         face_finish(r, ld3(pos), ld3(pos + 3), ld3(pos + 6), sc.face_uv + (m.face_off + prim) * 6, t, u, v, c);
     }
     return hit;
@@ -194,6 +203,7 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
                 h.c.t = t; h.c.u = u; h.c.v = v;
                 h.node = i;
                 h.leaf = p;
+                h.rec_leaf = p;
                 h.prim = sc.prim_face[m.prim_off + p];
                 hit = true;
             }
@@ -201,13 +211,14 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
         }
         if (cull && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
         Col c;
-        int prim;
-        const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, cnt, ls, false);
+        int prim, leaf;
+        const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, leaf, cnt, ls, false);
         if (got && c.t < min_dist) {
             min_dist = c.t;
             h.c = c;
             h.node = i;
             h.prim = prim;
+            h.rec_leaf = leaf;
             hit = true;
         }
     }
@@ -222,9 +233,8 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
 // the one whose shape was hit.  Reference mode runs the full closest-hit Collide per node as
 // the reference does; fast mode stops at the first face hit.
 template <int MODE>
-RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self_node, LdsStack ls) {
+RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self_node, LdsStack ls, VisitCounts& cnt) {
     const DNode self = sc.nodes[self_node];
-    VisitCounts cnt{0, 0};
     V3 inv = mk(0, 0, 0);
     if (MODE == RT_MODE_FAST) inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     for (int i = 0; i < sc.n_nodes; i++) {
@@ -238,8 +248,8 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
             continue;
         }
         Col c;
-        int prim;
-        if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, cnt, ls, false)) return true;
+        int prim, leaf;
+        if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, leaf, cnt, ls, false)) return true;
     }
     return false;
 }
@@ -323,6 +333,11 @@ RT_DEV void wave_tally(Counters* c, uint32_t total, uint32_t left, uint32_t exce
         if (left) atomicAdd(&t.left, (unsigned long long)left);
         if (exceeded) atomicAdd(&t.exceeded, (unsigned long long)exceeded);
     }
+}
+
+// The last thing a kernel does with its VisitCounts: one atomic per wave if any lane's traversal stack ran full.
+RT_DEV void report_overflow(Counters* c, const VisitCounts& vc) {
+    if (__ballot(vc.overflow) != 0 && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(true)) - 1)) atomicAdd(&c->errors.v, 1u);
 }
 
 RT_DEV void film_add(double* film, uint32_t pixel, V3 v) {
@@ -437,7 +452,7 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
         const uint32_t out_stripe = (uint32_t)c * kQueueStripes + stripe;
         uint32_t base = 0;
         if (n0 + n1 != 0) {
-            if (lane == 0) base = atomicAdd(&q.counters->next_cursor[out_stripe].v, n0 + n1);
+            if (lane == 0) base = atomicAdd(&q.counters->ray_cursor[out][out_stripe].v, n0 + n1);
             base = __shfl(base, 0, 64);
         }
         const uint32_t first = out_stripe * q.ray_stripe_cap;
@@ -476,9 +491,8 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
 // Returns -1 = invalid ray, 0 = the ray left the scene, 1 = hit an emitting-only material
 // (`emission` set), 2 = hit needs Material.Resolve (`h` set).
 template <int MODE, bool MESH_ONLY, bool PACKET = false>
-RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, LdsStack ls) {
+RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, LdsStack ls, VisitCounts& cnt) {
     if (bad3(r.o) || bad3(r.d)) return -1;  // render.go:147-150
-    VisitCounts cnt{0, 0};
 #ifdef RT_VISIT_STATS
     const long long closest_t0 = clock64();
 #endif
@@ -503,7 +517,7 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // pass, traced by one wave (lane p of it).  See k_primary for how lanes are dealt to samples and pixels.
 template <int MODE, bool MESH_ONLY, bool SHADE>
 RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, double* __restrict__ film, long long v,
-                         uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left, uint32_t& rot) {
+                         uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left, uint32_t& rot, VisitCounts& vc) {
     const int lanes_s = 1 << pass.log2_s;       // lanes (= samples in flight) per pixel
     const int px_per_iter = 64 >> pass.log2_s;  // pixels a wave traces at a time
     const int my_px = p >> pass.log2_s, my_s = p & (lanes_s - 1);
@@ -557,7 +571,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                 RT_STAT(13, clock64() - round_t0);
 #endif
                 V3 em;
-                const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST>(sc, r, mk(1, 1, 1), h, em, ls);
+                const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST>(sc, r, mk(1, 1, 1), h, em, ls, vc);
                 if (what == 1) { acc_lds[0] += em.x; acc_lds[64] += em.y; acc_lds[128] += em.z; }
                 want = what == 2;
                 missed = what == 0;
@@ -570,7 +584,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
             n_left += (uint32_t)__popcll(__ballot(missed));
             if (SHADE) {
                 // successive rounds of a wave append to successive stripes: over a launch every stripe receives its share
-                const V3 em2 = shade_lane(sc, pass, q, 0, rot++ & (kQueueStripes - 1), want, r, ps, h);
+                const V3 em2 = shade_lane(sc, pass, q, 1, rot++ & (kQueueStripes - 1), want, r, ps, h);
                 if (want) { acc_lds[0] += em2.x; acc_lds[64] += em2.y; acc_lds[128] += em2.z; }
             }
 #ifdef RT_VISIT_STATS
@@ -625,6 +639,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
     const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
     uint32_t n_total = 0, n_left = 0;
     uint32_t rot = blockIdx.x;  // stripe of the append queues this wave's next round writes to
+    VisitCounts vc{0, 0};
     // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
     auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
         const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
@@ -660,7 +675,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         const long long t_start = pass.cost ? clock64() : 0;
         sub = __shfl(sub, 0, 64);
         primary_item<MODE, MESH_ONLY, SHADE>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
-                                             reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left, rot);
+                                             reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left, rot, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
     if (p == 0) {  // the tallies are per wave already
@@ -668,9 +683,13 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         if (n_total) atomicAdd(&t.total, (unsigned long long)n_total);
         if (n_left) atomicAdd(&t.left, (unsigned long long)n_left);
     }
+    report_overflow(counters, vc);
 }
 
-template <int MODE, bool MESH_ONLY, int WAVES>
+// tracePath for one generation of scattered rays in a scene WITHOUT any mesh, one ray per lane: closest hit over the
+// nodes, Material.Resolve, children and surface point appended.  Nothing walks a tree here, so the lanes of a wave stay
+// together and the hit never has to leave the registers (scenes with a mesh go through k_walk and k_shade below).
+template <int MODE, int WAVES>
 __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDesc pass, Queues q, int in, RayStripeCounts cnt, double* __restrict__ film) {
     // blockIdx.y is the stripe of rays[in] this wave reads; its children go to stripe (x + y) % 32 of their class, so
     // of the waves that share an x at most gridDim.y / 32 write to the same stripe
@@ -685,6 +704,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDes
     PathState ps;
     ps.pixel = 0xffffffffu;
     V3 add = mk(0, 0, 0);
+    VisitCounts vc{0, 0};
     if (live) {
         r.o = mk(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
         r.d = mk(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
@@ -694,7 +714,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDes
         ps.path = rays.path[i];
         ps.depth_n = rays.depth_n[i];
         V3 em;
-        const int what = trace_one<MODE, MESH_ONLY>(sc, r, ps.rad, h, em, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs});
+        const int what = trace_one<MODE, false>(sc, r, ps.rad, h, em, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc);
         if (what == 0) n_left = 1;
         if (what == 1) add = em;
         want = what == 2;
@@ -703,6 +723,386 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDes
     if (want) add = em2;
     film_add_wave(film, ps.pixel, add);
     wave_tally(q.counters, 0, n_left, 0);  // the rays of this launch themselves are counted by the host
+    report_overflow(q.counters, vc);
+}
+
+// ---- scattered rays: k_walk (closest hits, lanes refilled as they finish) and k_shade (the rest of tracePath) ----
+
+// The TransformedShape chain of a node's shape (shape_transformed_shape.go:26-57), innermost shape last.
+struct Chain {
+    int xform[4];
+    int n;
+    int kind, index;  // the innermost shape
+};
+
+// Takes the ray through each inverse transform (direction not renormalised, so t is preserved).
+RT_DEV void chain_down(const DScene& sc, int kind, int index, Ray& r, Chain& ch) {
+    ch.n = 0;
+    while (kind == RT_SHAPE_TRANSFORMED && ch.n < 4) {
+        const DTransformed& x = sc.xforms[index];
+        r.o = xf_point(x.inv, r.o);
+        r.d = xf_vector(x.inv, r.d);
+        ch.xform[ch.n++] = index;
+        kind = x.child_kind;
+        index = x.child_index;
+    }
+    ch.kind = kind;
+    ch.index = index;
+}
+
+// Hit point and normal back through the forward transforms.
+RT_DEV void chain_up(const DScene& sc, const Chain& ch, Col& c) {
+    for (int j = ch.n - 1; j >= 0; j--) {
+        const DTransformed& x = sc.xforms[ch.xform[j]];
+        c.at = xf_point(x.fwd, c.at);
+        c.normal = unit(xf_vector(x.fwd, c.normal));
+    }
+}
+
+// Collide of an innermost shape that is not a mesh, in its own frame.
+RT_DEV bool simple_collide(const DScene& sc, int kind, int index, const Ray& r, double tmin, double tmax, Col& c) {
+    switch (kind) {
+        case RT_SHAPE_SPHERE: return sphere_collide(sc.spheres[index], r, tmin, tmax, c);
+        case RT_SHAPE_QUAD: return quad_collide(sc.quads[index], r, tmin, tmax, c);
+        case RT_SHAPE_CYLINDER: return cylinder_collide(sc.cylinders[index], r, tmin, tmax, c);
+        case RT_SHAPE_TRIANGLE: return tri_collide(sc.tris[index], r, tmin, tmax, c);
+        default: return false;
+    }
+}
+
+// Lanes a wave of k_walk wants idle before it fetches new rays for them (fetching and setting up a ray runs with
+// only those lanes enabled, walking runs with the others).
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 20
+#endif
+
+// tracePath's closest hit (render.go:155-169) for one generation of scattered rays.
+//
+// Scattered rays of a wave have nothing in common: their walks through a mesh's tree differ in length by an order of
+// magnitude, and a wave that traces 64 rays to the end runs most of the time with a quarter of its lanes.  So the
+// waves are persistent and a lane that has finished its ray gets the next one: whenever RT_REFILL_MIN lanes of a wave
+// are idle it reserves that many rays of a queue stripe (one atomic), hands them out, and walks on.  What a lane
+// carries between rounds is its walk state (WalkLane, the LDS stack) and the best hit so far; the ray itself stays in
+// the queue.  Per ray: every node that holds no mesh is tested when the ray is fetched (a short loop), then the trees
+// of the nodes that do (sc.walk_nodes) are walked one after the other in rounds of walk_round().  Finished rays that
+// hit something leave a record (ray, node, face, t, barycentrics) in q.hits, in blocks of kClaim entries the wave
+// reserves per stripe, for k_shade; misses are only counted.  Reference mode keeps the reference's order (nodes in
+// order, left-first walk) and does all of it when the ray is fetched.
+// The loop ends for every wave: the claim cursors only grow, and a wave that finds every stripe drained stops fetching
+// and finishes the rays it holds.
+template <int MODE, bool MESH_ONLY, int WAVES>
+__global__ void __launch_bounds__(kTraceBlock, WAVES) k_walk(DScene sc, Queues q, int in, RayStripeCounts cnt, int n_stripes) {
+    const RayQ& rays = q.rays[in];
+    const HitQ& hq = q.hits;
+    Counters* const C = q.counters;
+    const int lane = (int)threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const WalkStack stack{dyn_lds + threadIdx.x, q.walk_spill + (size_t)blockIdx.x * (size_t)sc.stack_pairs * 64 + threadIdx.x, sc.stack_pairs};
+    // wave-uniform: the blocks of rays and of hit records this wave has reserved
+    int in_stripe = (int)(blockIdx.x % (unsigned)n_stripes), drained = 0;
+    uint32_t in_pos = 0, in_end = 0;
+    int out_stripe = (int)(blockIdx.x % (unsigned)kQueueStripes);
+    uint32_t out_pos = 0, out_end = 0;
+    bool exhausted = false;
+    // per lane
+    uint32_t slot = kNoRay;
+    WalkLane w;
+    w.cur = kFastEmpty;
+    w.sp = 0;
+    w.base = 0;
+    BestHit best{kMaxFloat, -1, -1};
+    int32_t walk_k = 0, walk_node = 0;  // position in sc.walk_nodes of the tree being walked, and that node
+    uint32_t n_left = 0;
+    VisitCounts vc{0, 0};
+
+    // Reserves up to `want` rays of the stripe the wave stands on, moving on over drained stripes; false when every
+    // stripe is drained.  A wave reserves only what its idle lanes take at once: rays held back in a private block would
+    // be out of reach of the waves that run dry at the end of the launch.
+    auto claim_in = [&](uint32_t want) -> bool {
+        while (drained < n_stripes) {
+            const uint32_t n = cnt.n[in_stripe];
+            uint32_t base = 0;
+            if (lane == 0 && n != 0) base = atomicAdd(&C->in_cursor[in_stripe].v, want);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, 0, 64));
+            if (n != 0 && base < n) {
+                in_pos = base;
+                in_end = base + want < n ? base + want : n;
+                drained = 0;
+                return true;
+            }
+            in_stripe = in_stripe + 1 == n_stripes ? 0 : in_stripe + 1;
+            drained++;
+        }
+        return false;
+    };
+    auto claim_out = [&]() -> bool {  // a block of hit records to fill; a full stripe sends the wave on to the next one
+        for (int tries = 0; tries < kQueueStripes; tries++) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&C->hit_cursor[out_stripe].v, kClaim);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, 0, 64));
+            if (base + kClaim <= q.hit_stripe_cap) {
+                out_pos = base;
+                out_end = base + kClaim;
+                return true;
+            }
+            out_stripe = out_stripe + 1 == kQueueStripes ? 0 : out_stripe + 1;
+        }
+        return false;
+    };
+    auto load_ray = [&]() { return Ray{mk(rays.o[0][slot], rays.o[1][slot], rays.o[2][slot]), mk(rays.d[0][slot], rays.d[1][slot], rays.d[2][slot])}; };
+    // the next tree of this lane's ray that its ray can reach (fast mode); w.cur stays kFastEmpty when there is none
+    auto next_walk = [&](const Ray& r) {
+        while (walk_k < sc.n_walk_nodes) {
+            const int node = MESH_ONLY ? walk_k : sc.walk_nodes[walk_k];
+            const DNode nd = sc.nodes[node];
+            Ray lr = r;
+            int mesh = nd.index;
+            if (!MESH_ONLY) {
+                Chain ch;
+                chain_down(sc, nd.kind, nd.index, lr, ch);
+                mesh = ch.index;
+            }
+            if (walk_begin(sc.meshes[mesh], lr, kEps, best.t, w)) {
+                walk_node = node;
+                return;
+            }
+            walk_k++;
+        }
+    };
+
+#ifdef RT_VISIT_STATS
+    long long ws_refill = 0, ws_walk = 0, ws_out = 0, ws_rounds = 0, ws_lanes = 0, ws_iters = 0, ws_fetched = 0;
+    const long long ws_begin = clock64();
+#endif
+    for (;;) {
+#ifdef RT_VISIT_STATS
+        const long long ws_t0 = clock64();
+        ws_iters++;
+#endif
+        // ---- hand new rays to the idle lanes
+        unsigned long long idle = __ballot(slot == kNoRay);
+        bool fresh = false;
+        if (!exhausted && (__popcll(idle) >= RT_REFILL_MIN)) {
+            while (idle != 0) {
+                if (in_pos == in_end && !claim_in((uint32_t)__popcll(idle))) {
+                    exhausted = true;
+                    break;
+                }
+                const uint32_t want = (uint32_t)__popcll(idle), have = in_end - in_pos;
+                const uint32_t take = want < have ? want : have;
+                const uint32_t rank = (uint32_t)__popcll(idle & below);
+                if (slot == kNoRay && rank < take) {
+                    slot = (uint32_t)in_stripe * q.ray_stripe_cap + in_pos + rank;
+                    fresh = true;
+                }
+                in_pos += take;
+                idle = __ballot(slot == kNoRay);
+            }
+        }
+        if (fresh) {
+            const Ray r = load_ray();
+            best = BestHit{kMaxFloat, -1, -1};
+            walk_k = 0;
+            w.cur = kFastEmpty;
+            w.sp = 0;
+            w.base = 0;
+            if (bad3(r.o) || bad3(r.d)) {
+                best.node = -2;  // render.go:147-150: an invalid ray is black and counts neither as a hit nor as having left
+            } else if (MODE == RT_MODE_REFERENCE) {
+                for (int i = 0; i < sc.n_nodes; i++) {  // nodes in order, Shape.Collide(r, eps, minDist), keep when c.t < minDist
+                    const DNode nd = sc.nodes[i];
+                    Ray lr = r;
+                    Chain ch;
+                    chain_down(sc, nd.kind, nd.index, lr, ch);
+                    if (ch.kind == RT_SHAPE_MESH) {
+                        double t, u, v;
+                        int p = 0;
+                        if (mesh_collide_ref(sc, sc.meshes[ch.index], lr, kEps, best.t, p, t, u, v, vc) && t < best.t) best = BestHit{t, i, p};
+                    } else {
+                        Col c;
+                        if (simple_collide(sc, ch.kind, ch.index, lr, kEps, best.t, c) && c.t < best.t) best = BestHit{c.t, i, -1};
+                    }
+                }
+            } else {
+                if (!MESH_ONLY) {  // every node without a mesh, now; a node whose padded bounds the ray misses is skipped
+                    const V3 inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+                    for (int i = 0; i < sc.n_nodes; i++) {
+                        const DNode nd = sc.nodes[i];
+                        if (nd.pad) continue;  // holds a mesh: walked below
+                        if (!node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, kEps, best.t)) continue;
+                        Ray lr = r;
+                        Chain ch;
+                        chain_down(sc, nd.kind, nd.index, lr, ch);
+                        Col c;
+                        if (simple_collide(sc, ch.kind, ch.index, lr, kEps, best.t, c) && c.t < best.t) best = BestHit{c.t, i, -1};
+                    }
+                }
+                next_walk(r);
+            }
+        }
+#ifdef RT_VISIT_STATS
+        const long long ws_t1 = clock64();
+        ws_refill += ws_t1 - ws_t0;
+        ws_fetched += __popcll(__ballot(fresh));
+#endif
+        // ---- walk
+        unsigned long long walking = __ballot(w.cur != kFastEmpty);
+        while (walking != 0) {
+#ifdef RT_VISIT_STATS
+            ws_rounds++;
+            ws_lanes += __popcll(walking);
+#endif
+            if (w.cur != kFastEmpty) {
+                walk_round<false, kWalkRing>(sc, w, walk_node, kEps, best, stack, vc.overflow);
+                if (w.cur == kFastEmpty && sc.n_walk_nodes > 1) {  // this tree is done: on to the next one the ray can reach
+                    walk_k++;
+                    next_walk(load_ray());
+                }
+            }
+            walking = __ballot(w.cur != kFastEmpty);
+            if (!exhausted && __popcll(walking) <= 64 - RT_REFILL_MIN) break;
+        }
+#ifdef RT_VISIT_STATS
+        const long long ws_t2 = clock64();
+        ws_walk += ws_t2 - ws_t1;
+#endif
+        // ---- finished rays: misses are counted, hits leave a record
+        const bool fin = slot != kNoRay && w.cur == kFastEmpty;
+        if (fin && best.node == -1) n_left++;
+#ifdef RT_VISIT_STATS
+        if (fin) {  // histogram of inner nodes per ray, buckets of powers of two, and the longest walk
+            int b = 0;
+            while ((2u << b) <= w.steps && b < 13) b++;
+            atomicAdd(&g_trace_stats[(blockIdx.x + threadIdx.x) & 63u][32 + b], 1ull);
+            atomicMax(&g_trace_stats[0][47], (unsigned long long)w.steps);
+            w.steps = 0;
+        }
+#endif
+        bool pending = fin && best.node >= 0;
+        unsigned long long out = __ballot(pending);
+        while (out != 0) {
+            if (out_pos == out_end && !claim_out()) {
+                if (lane == 0) atomicAdd(&C->errors.v, 1u);  // every stripe of the hit queue is full: the host sizes it so that this cannot happen
+                break;
+            }
+            const uint32_t want = (uint32_t)__popcll(out), have = out_end - out_pos;
+            const uint32_t take = want < have ? want : have;
+            const uint32_t rank = (uint32_t)__popcll(out & below);
+            if (pending && rank < take) {
+                const size_t at = (size_t)out_stripe * q.hit_stripe_cap + out_pos + rank;
+                hq.ray[at] = slot;
+                hq.node[at] = best.node;
+                hq.leaf[at] = best.leaf;
+                hq.t[at] = best.t;
+                pending = false;
+            }
+            out_pos += take;
+            out = __ballot(pending);
+        }
+        if (fin) slot = kNoRay;
+#ifdef RT_VISIT_STATS
+        ws_out += clock64() - ws_t2;
+#endif
+        if (exhausted && __ballot(slot != kNoRay) == 0) break;
+    }
+#ifdef RT_VISIT_STATS
+    RT_TSTAT(48, 1);
+    RT_TSTAT(49, clock64() - ws_begin);
+    RT_TSTAT(50, ws_refill);
+    RT_TSTAT(51, ws_walk);
+    RT_TSTAT(52, ws_out);
+    RT_TSTAT(53, ws_rounds);
+    RT_TSTAT(54, ws_lanes);
+    RT_TSTAT(55, ws_iters);
+    RT_TSTAT(56, ws_fetched);
+#endif
+    // the rest of the last block of hit records stays unused
+    for (uint32_t i = out_pos + (uint32_t)lane; i < out_end; i += 64) hq.ray[(size_t)out_stripe * q.hit_stripe_cap + i] = kNoRay;
+    wave_tally(C, 0, n_left, 0);  // the rays of this launch themselves are counted by the host
+    report_overflow(C, vc);
+}
+
+// The second half of tracePath (render.go:174-183) for the hits k_walk recorded: attributes of the hit, Material.Resolve,
+// children appended to the next generation, the surface point queued for the light loop, emission added to the film.
+// Persistent waves deal the chunks of 64 records among themselves round-robin (the work per record is even).
+template <int MODE, bool MESH_ONLY, int WAVES>
+__global__ void __launch_bounds__(kTraceBlock, WAVES) k_shade(DScene sc, PassDesc pass, Queues q, int in, double* __restrict__ film) {
+    const RayQ& rays = q.rays[in];
+    const HitQ& hq = q.hits;
+    Counters* const C = q.counters;
+    const Counters::Cursor* const counts = C->hit_cursor;
+    const uint32_t lane = threadIdx.x;
+    uint32_t most = 0;
+    for (int s = 0; s < kQueueStripes; s++) {
+        const uint32_t n = counts[s].v;
+        most = most > n ? most : n;
+    }
+    most = most < q.hit_stripe_cap ? most : q.hit_stripe_cap;
+    const uint32_t chunks = (most + 63u) / 64u * (uint32_t)kQueueStripes;  // chunk c: records [64 (c / stripes), +64) of stripe c % stripes
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const uint32_t stripe = c & (kQueueStripes - 1), k = c / kQueueStripes;
+        uint32_t n_s = counts[stripe].v;
+        n_s = n_s < q.hit_stripe_cap ? n_s : q.hit_stripe_cap;
+        const uint32_t i = k * 64u + lane;
+        const size_t at = (size_t)stripe * q.hit_stripe_cap + i;
+        uint32_t slot = kNoRay;
+        if (i < n_s) slot = hq.ray[at];
+        const bool live = slot != kNoRay;
+        if (__ballot(live) == 0) continue;
+        bool want = false;
+        Ray r;
+        SceneHit h;
+        PathState ps;
+        ps.pixel = 0xffffffffu;
+        V3 add = mk(0, 0, 0);
+        if (live) {
+            r.o = mk(rays.o[0][slot], rays.o[1][slot], rays.o[2][slot]);
+            r.d = mk(rays.d[0][slot], rays.d[1][slot], rays.d[2][slot]);
+            ps.rad = mk(rays.rad[0][slot], rays.rad[1][slot], rays.rad[2][slot]);
+            ps.pixel = rays.pixel[slot];
+            ps.sample = rays.sample[slot];
+            ps.path = rays.path[slot];
+            ps.depth_n = rays.depth_n[slot];
+            h.node = hq.node[at];
+            h.leaf = -1;
+            h.prim = 0;
+            const int32_t leaf = hq.leaf[at];
+            const double t = hq.t[at];
+            const DNode nd = sc.nodes[h.node];
+            const rt_material& m = sc.materials[nd.material];
+            const bool terminal = terminal_kind(m.kind);
+            Ray lr = r;
+            Chain ch;
+            if (MESH_ONLY) { ch.n = 0; ch.kind = RT_SHAPE_MESH; ch.index = nd.index; }
+            else chain_down(sc, nd.kind, nd.index, lr, ch);
+            bool ok = true;
+            if (ch.kind == RT_SHAPE_MESH) {
+                // Face.Collide on the recorded face, limited to the recorded distance: the same t again, and the barycentrics
+                const DMesh& mesh = sc.meshes[ch.index];
+                const double* pos = sc.prim_pos + (mesh.prim_off + leaf) * 9;
+                const V3 p0 = ld3(pos), p1 = ld3(pos + 3), p2 = ld3(pos + 6);
+                double t2, u, v;
+                ok = mt_core(lr, p0, p1, p2, 1e-8, kEps, t, t2, u, v);
+                h.prim = sc.prim_face[mesh.prim_off + leaf];
+                face_finish(lr, p0, p1, p2, sc.face_uv + (mesh.face_off + h.prim) * 6, t, u, v, h.c);
+            } else {
+                // Any other shape: k_walk kept the distance only.  The shape's Collide limited to that distance returns
+                // the same hit again (each returns its nearest root inside [tmin, tmax]).
+                ok = simple_collide(sc, ch.kind, ch.index, lr, kEps, t, h.c);
+                if (ok && ch.kind == RT_SHAPE_SPHERE && (ch.n > 0 || material_reads_uv(sc, nd.material))) sphere_uv(sc.spheres[ch.index], h.c);
+            }
+            if (!ok) {
+                atomicAdd(&C->errors.v, 1u);
+            } else {
+                if (ch.n > 0) chain_up(sc, ch, h.c);
+                if (terminal) add = terminal_emission(sc, m, h.c, ps.rad);
+                else want = true;
+            }
+        }
+        const V3 em2 = shade_lane(sc, pass, q, 1 - in, (stripe + k) & (kQueueStripes - 1), want, r, ps, h);
+        if (want) add = em2;
+        film_add_wave(film, ps.pixel, add);
+    }
 }
 
 // ComputeDirectLighting's loop body for one (surface point, light) pair
@@ -716,6 +1116,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_
     const uint32_t i = stripe * q.surf_stripe_cap + at_stripe;
     uint32_t pixel = 0xffffffffu;
     V3 contrib = mk(0, 0, 0);
+    VisitCounts vc{0, 0};
     if (live) {
         pixel = q.surfs.pixel[i];
         const rt_light L = sc.lights[light];
@@ -727,7 +1128,9 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_
         dir = dir / dist;
         const V3 wi = m.kind == RT_MAT_LAMBERTIAN ? dir : unit(dir);
         Ray sh{p + n * kEps, wi};
-        if (scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs})) {
+        const bool occ = scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc);
+        RT_WFLUSH(vc);
+        if (occ) {
             // in shadow: nothing to add
         } else if (m.kind == RT_MAT_LAMBERTIAN) {
             const double ndl = go_max(0, dot(n, dir));
@@ -751,6 +1154,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_
         }
     }
     film_add_wave(film, pixel, contrib);
+    report_overflow(q.counters, vc);
 }
 
 // renderPixel's quantisation (render.go:218-224).
@@ -820,24 +1224,25 @@ static inline size_t stack_bytes(const DScene& sc, int mode) {
 // rounds over the 8 XCDs.
 template <typename K>
 static unsigned persistent_grid(K kernel, size_t lds) {
-    // the answer depends only on (device, kernel, LDS bytes): keep the last one
-    static thread_local const void* cached_kernel = nullptr;
-    static thread_local int cached_device = -1;
-    static thread_local size_t cached_lds = 0;
-    static thread_local unsigned cached_grid = 0;
+    // the answer depends only on (device, kernel, LDS bytes)
+    static std::mutex mutex;
+    static std::map<std::tuple<const void*, int, size_t>, unsigned> cache;
     int device = 0;
     (void)hipGetDevice(&device);
-    if (reinterpret_cast<const void*>(kernel) == cached_kernel && device == cached_device && lds == cached_lds && cached_grid) return cached_grid;
+    const auto key = std::make_tuple(reinterpret_cast<const void*>(kernel), device, lds);
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        const auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
     int cus = 0, per_cu = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kTraceBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
-    if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] primary: %d CUs x %d workgroups, %zu B LDS each\n", cus, per_cu, lds);
-    const unsigned n = (unsigned)std::max(cus, 8) * (unsigned)per_cu;
-    cached_kernel = reinterpret_cast<const void*>(kernel);
-    cached_device = device;
-    cached_lds = lds;
-    cached_grid = n & ~7u;
-    return cached_grid;
+    if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] persistent kernel %p: %d CUs x %d workgroups, %zu B LDS each\n", reinterpret_cast<const void*>(kernel), cus, per_cu, lds);
+    const unsigned n = ((unsigned)std::max(cus, 8) * (unsigned)per_cu) & ~7u;
+    std::lock_guard<std::mutex> lock(mutex);
+    cache[key] = n;
+    return n;
 }
 
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
@@ -876,18 +1281,33 @@ static uint32_t most(const StripeCounts& c) {
 
 void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int in, const RayStripeCounts& n, int mode, bool mesh_only, double* film,
                   hipStream_t s) {
+    uint64_t total = 0;
     uint32_t most_n = 0;
-    for (uint32_t v : n.n) most_n = std::max(most_n, v);
-    if (most_n == 0) return;
-    const dim3 grid(trace_blocks(most_n), sc.walk_classes ? kRayStripes : kQueueStripes), block(kTraceBlock);
-    const size_t lds = stack_bytes(sc, mode);
+    for (uint32_t v : n.n) { total += v; most_n = std::max(most_n, v); }
+    if (total == 0) return;
+    const int n_stripes = sc.walk_classes ? kRayStripes : kQueueStripes;
+    if (sc.n_meshes == 0) {  // no tree to walk: one fused launch, one ray per lane, blockIdx.y = stripe
+        const dim3 grid(trace_blocks(most_n), n_stripes), block(kTraceBlock);
+        if (mode == RT_MODE_REFERENCE) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, 2>), grid, block, 0, s, sc, pass, q, in, n, film);
+        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, RT_TRACE_SHAPES_WAVES>), grid, block, 0, s, sc, pass, q, in, n, film);
+        return;
+    }
+    const size_t lds = mode == RT_MODE_FAST ? (size_t)2 * kWalkRing * kTraceBlock * sizeof(int32_t) : 0;  // the top of every lane's walk stack
+    const unsigned want_waves = (unsigned)std::min<uint64_t>((total + 63) / 64, (uint64_t)kWalkWavesMax);
+    auto walk = [&](auto kernel) {
+        const unsigned waves = std::max(1u, std::min(persistent_grid(kernel, lds), want_waves));
+        hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), lds, s, sc, q, in, n, n_stripes);
+    };
+    auto shade = [&](auto kernel) {
+        const unsigned waves = std::max(1u, std::min(persistent_grid(kernel, 0), want_waves + (unsigned)kQueueStripes));
+        hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), 0, s, sc, pass, q, in, film);
+    };
     if (mode == RT_MODE_REFERENCE) {
-        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, true, 2>), grid, block, lds, s, sc, pass, q, in, n, film);
-        else hipLaunchKernelGGL((k_trace<RT_MODE_REFERENCE, false, 2>), grid, block, lds, s, sc, pass, q, in, n, film);
+        if (mesh_only) { walk(k_walk<RT_MODE_REFERENCE, true, 2>); shade(k_shade<RT_MODE_REFERENCE, true, 2>); }
+        else { walk(k_walk<RT_MODE_REFERENCE, false, 2>); shade(k_shade<RT_MODE_REFERENCE, false, 2>); }
     } else {
-        if (mesh_only) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, true, RT_TRACE_WAVES>), grid, block, lds, s, sc, pass, q, in, n, film);
-        else if (sc.n_meshes > 0) hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false, RT_TRACE_WAVES>), grid, block, lds, s, sc, pass, q, in, n, film);
-        else hipLaunchKernelGGL((k_trace<RT_MODE_FAST, false, RT_TRACE_SHAPES_WAVES>), grid, block, lds, s, sc, pass, q, in, n, film);
+        if (mesh_only) { walk(k_walk<RT_MODE_FAST, true, RT_TRACE_WAVES>); shade(k_shade<RT_MODE_FAST, true, RT_SHADE_WAVES>); }
+        else { walk(k_walk<RT_MODE_FAST, false, RT_TRACE_WAVES>); shade(k_shade<RT_MODE_FAST, false, RT_SHADE_WAVES>); }
     }
 }
 
@@ -906,6 +1326,18 @@ void debug_packet_stats(unsigned long long* out8, bool reset) {  // out8: 16 val
     if (reset) {
         unsigned long long zero[16] = {};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_packet_stats), zero, sizeof(zero));
+    }
+}
+void debug_trace_stats(unsigned long long* out32, bool reset) {
+    static unsigned long long all[64][64];
+    (void)hipMemcpyFromSymbol(all, HIP_SYMBOL(g_trace_stats), sizeof(all));
+    for (int i = 0; i < 64; i++) {
+        out32[i] = 0;
+        for (int s = 0; s < 64; s++) out32[i] += all[s][i];
+    }
+    if (reset) {
+        std::memset(all, 0, sizeof(all));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_stats), all, sizeof(all));
     }
 }
 #endif

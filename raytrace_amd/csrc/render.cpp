@@ -82,6 +82,13 @@ void carve(RayQ& r, void* base, size_t cap) {
     r.path = reinterpret_cast<uint32_t*>(p); p += cap * 4;
     r.depth_n = reinterpret_cast<uint32_t*>(p);
 }
+void carve(HitQ& h, void* base, size_t cap) {
+    char* p = static_cast<char*>(base);
+    h.t = reinterpret_cast<double*>(p); p += cap * 8;
+    h.ray = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+    h.node = reinterpret_cast<int32_t*>(p); p += cap * 4;
+    h.leaf = reinterpret_cast<int32_t*>(p);
+}
 void carve(SurfQ& s, void* base, size_t cap) {
     char* p = static_cast<char*>(base);
     for (int k = 0; k < 3; k++) { s.p[k] = reinterpret_cast<double*>(p); p += cap * 8; }
@@ -118,7 +125,7 @@ int ensure_work(const rt_scene* sc, Replica& rep) {
     w->q = (uint32_t)env_size("RT_QUEUE_RAYS", (size_t)1 << 25);
     if (w->q < 64 * 64) w->q = 64 * 64;
     const size_t q = w->q;
-    char *rays0 = nullptr, *rays1 = nullptr, *surfs = nullptr;
+    char *rays0 = nullptr, *rays1 = nullptr, *surfs = nullptr, *hits = nullptr;
     // a scene that never shades needs none of the queues (kernels still get valid pointers)
     const size_t qq = sc->all_terminal ? 64 : q;
     // Stripe capacities.  A primary launch traces at most q paths in rounds of a wave that are at least 90 % full, and
@@ -135,6 +142,13 @@ int ensure_work(const rt_scene* sc, Replica& rep) {
     HIP_TRY(w->mem.alloc((size_t)w->ray_stripes * ray_cap * kRayBytes, &rays0));
     HIP_TRY(w->mem.alloc((size_t)w->ray_stripes * ray_cap * kRayBytes, &rays1));
     HIP_TRY(w->mem.alloc(kQueueStripes * surf_cap * kSurfBytes, &surfs));
+    // Hit records: a launch traces at most q rays, and every wave of k_walk may leave one reserved block partly unused;
+    // a wave that finds a stripe full moves on to the next, so only the sum over the stripes has to fit.
+    const size_t hit_cap = (sc->all_terminal || rep.dev.n_meshes == 0) ? kClaim : ((qq + (size_t)kWalkWavesMax * kClaim) / kQueueStripes / kClaim + 2) * kClaim;
+    HIP_TRY(w->mem.alloc(kQueueStripes * hit_cap * kHitBytes, &hits));
+    carve(w->queues.hits, hits, kQueueStripes * hit_cap);
+    w->queues.hit_stripe_cap = (uint32_t)hit_cap;
+    if (rep.dev.n_meshes > 0 && !sc->all_terminal) HIP_TRY(w->mem.alloc((size_t)kWalkWavesMax * 64 * (size_t)rep.dev.stack_pairs, &w->queues.walk_spill));
     HIP_TRY(w->mem.alloc(1, &w->queues.counters));
     carve(w->queues.rays[0], rays0, (size_t)w->ray_stripes * ray_cap);
     carve(w->queues.rays[1], rays1, (size_t)w->ray_stripes * ray_cap);
@@ -488,10 +502,17 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
         HIP_TRY(hipMemcpyAsync(&host, q.counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(events.drain());
+        if (host.errors.v != 0)
+            return fail(RT_ERR_DEVICE, "internal error counted by a kernel (" + std::to_string(host.errors.v) + "): a traversal stack or a hit queue ran full");
         return RT_OK;
     };
-    auto reset_cursors = [&]() -> int {  // zero the append and tile cursors, keep the statistics
-        HIP_TRY(hipMemsetAsync(&q.counters->next_cursor[0], 0, sizeof(Counters) - offsetof(Counters, next_cursor), stream));
+    auto reset_cursors = [&]() -> int {  // zero every append, claim and tile cursor, keep the statistics
+        HIP_TRY(hipMemsetAsync(&q.counters->ray_cursor[0][0], 0, sizeof(Counters) - offsetof(Counters, ray_cursor), stream));
+        return RT_OK;
+    };
+    auto reset_for_trace = [&](int out) -> int {  // before a launch that traces one ray queue and appends to the other (`out`)
+        HIP_TRY(hipMemsetAsync(&q.counters->ray_cursor[out][0], 0, sizeof(q.counters->ray_cursor[out]), stream));
+        HIP_TRY(hipMemsetAsync(&q.counters->surf_cursor[0], 0, sizeof(Counters) - offsetof(Counters, surf_cursor), stream));
         return RT_OK;
     };
 
@@ -592,7 +613,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 continue;
             }
             // generations of scattered rays: the launch just queued left its children in rays[cur]
-            int cur = 0;
+            int cur = 1;
             for (;;) {
                 if (sc->cancel.load()) {
                     (void)hipStreamSynchronize(stream);
@@ -603,9 +624,10 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 StripeCounts surf_n{};
                 uint64_t n_surf = 0;
                 for (int k = 0; k < w.ray_stripes; k++) {
-                    rays_n.n[k] = host.next_cursor[k].v;
+                    rays_n.n[k] = host.ray_cursor[cur][k].v;
                     if (rays_n.n[k] > q.ray_stripe_cap) return fail(RT_ERR_DEVICE, "internal queue overflow");
                 }
+
                 for (int k = 0; k < kQueueStripes; k++) {
                     surf_n.n[k] = host.surf_cursor[k].v;
                     if (surf_n.n[k] > q.surf_stripe_cap) return fail(RT_ERR_DEVICE, "internal queue overflow");
@@ -655,11 +677,21 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                         n += take;
                     }
                 }
-                if (int rc = reset_cursors()) return rc;
+                if (int rc = reset_for_trace(1 - cur)) return rc;
                 HIP_TRY(events.next(&ev));
                 HIP_TRY(hipEventRecord(ev->a, stream));
                 launch_trace(rep.dev, pass, q, cur, rays_n, o->mode, sc->mesh_only, film, stream);
                 launched_rays += n;
+#ifdef RT_VISIT_STATS
+                if (std::getenv("RT_DEBUG")) {
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    unsigned long long ts[64];
+                    debug_trace_stats(ts, true);
+                    const double wv = ts[48] ? (double)ts[48] : 1.0;
+                    fprintf(stderr, "[rt] k_walk: %llu rays, %llu waves; per wave: %.0f cycles (refill %.0f, walk %.0f, output %.0f), %.1f loop iterations, %.1f rounds at %.1f lanes, %.1f rays fetched\n",
+                            (unsigned long long)n, ts[48], ts[49] / wv, ts[50] / wv, ts[51] / wv, ts[52] / wv, ts[55] / wv, ts[53] / wv, ts[53] ? (double)ts[54] / ts[53] : 0.0, ts[56] / wv);
+                }
+#endif
                 HIP_TRY(hipEventRecord(ev->b, stream));
                 HIP_TRY(hipGetLastError());
                 traverse_launches++;
@@ -690,6 +722,18 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 ps[0], ps[1] / w, ps[2] / w, ps[3] / w, ps[4] / w, ps[5] / w, ps[6] / w);
         fprintf(stderr, "[rt] wave rounds %llu: %.0f cycles each on average; walks %.0f cycles each (%.0f of them in leaves), %.1f %% of all round cycles\n",
                 ps[10], ps[9] / rounds, ps[8] / w, ps[11] / w, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0);
+        unsigned long long ts[64];
+        debug_trace_stats(ts, true);
+        auto d = [](unsigned long long a, unsigned long long b) { return b ? (double)a / (double)b : 0.0; };
+        fprintf(stderr, "[rt] k_walk inner nodes per ray, rays in [0,2) [2,4) ... [8192,inf): ");
+        for (int b = 0; b < 14; b++) fprintf(stderr, "%llu ", ts[32 + b]);
+        fprintf(stderr, "; longest %llu\n", ts[47]);
+        fprintf(stderr, "[rt] k_trace waves %llu, live lanes %.1f, lanes needing Resolve %.1f; cycles per wave: closest hit %.0f, Resolve + appends %.0f, film %.0f\n",
+                ts[8], d(ts[9], ts[8]), d(ts[11], ts[8]), d(ts[10], ts[8]), d(ts[12], ts[8]), d(ts[13], ts[8]));
+        fprintf(stderr, "[rt] per-lane closest walks: %llu waves at %.1f lanes; per wave %.1f inner steps at %.1f lanes, %.1f face steps at %.1f lanes\n",
+                ts[16], d(ts[17], ts[16]), d(ts[18], ts[16]), d(ts[19], ts[18]), d(ts[20], ts[16]), d(ts[21], ts[20]));
+        fprintf(stderr, "[rt] per-lane any-hit walks: %llu waves at %.1f lanes; per wave %.1f inner steps at %.1f lanes, %.1f face steps at %.1f lanes\n",
+                ts[22], d(ts[23], ts[22]), d(ts[24], ts[22]), d(ts[25], ts[24]), d(ts[26], ts[22]), d(ts[27], ts[26]));
         fprintf(stderr, "[rt] share of round cycles: ray generation %.1f %%, closest hit (set-up + walk) %.1f %%, rest (attributes, shading, film) %.1f %%\n",
                 100.0 * ps[13] / (double)ps[9], 100.0 * ps[12] / (double)ps[9], 100.0 * ((double)ps[9] - ps[13] - ps[12]) / (double)ps[9]);
     }

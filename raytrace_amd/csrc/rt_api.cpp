@@ -384,6 +384,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<DMesh> meshes(d->n_meshes);
     std::vector<RefNode> ref_nodes;
     std::vector<FastNode> fast_nodes;
+    std::vector<QNode> q_nodes;
     std::vector<double> prim_pos;
     std::vector<Tri32> prim_tri32;
     std::vector<int32_t> prim_face;
@@ -405,9 +406,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         m.pad = b.pad;
         m.radius = b.radius;
         m.pad2 = 0;
+        std::memcpy(m.grid_lo, b.grid_lo, sizeof(m.grid_lo));
+        std::memcpy(m.grid_step, b.grid_step, sizeof(m.grid_step));
         m.n_faces = (int32_t)d->meshes[i].n_faces;
         ref_nodes.insert(ref_nodes.end(), b.ref_nodes.begin(), b.ref_nodes.end());
         fast_nodes.insert(fast_nodes.end(), b.fast_nodes.begin(), b.fast_nodes.end());
+        q_nodes.insert(q_nodes.end(), b.q_nodes.begin(), b.q_nodes.end());
         prim_pos.insert(prim_pos.end(), b.prim_pos.begin(), b.prim_pos.end());
         prim_tri32.insert(prim_tri32.end(), b.prim_tri32.begin(), b.prim_tri32.end());
         prim_face.insert(prim_face.end(), b.prim_face.begin(), b.prim_face.end());
@@ -424,7 +428,6 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<rt_texture> textures(d->textures, d->textures + d->n_textures);
     std::vector<rt_light> lights(d->lights, d->lights + d->n_lights);
     sc->node_box = node_box;
-    sc->nodes = nodes;
     sc->meshes = meshes;
     sc->fast_nodes = fast_nodes;
     sc->all_terminal = true;
@@ -433,7 +436,21 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     sc->mesh_only = d->n_nodes > 0;
     for (const DNode& n : nodes)
         if (n.kind != RT_SHAPE_MESH) sc->mesh_only = false;
+    // nodes that hold a mesh, directly or under transforms (flagged in DNode::pad): the trees the scattered-ray kernel walks
+    std::vector<int32_t> walk_nodes;
+    for (uint64_t i = 0; i < d->n_nodes; i++) {
+        int kind = nodes[i].kind, index = nodes[i].index;
+        for (int depth = 0; kind == RT_SHAPE_TRANSFORMED && depth < 4; depth++) {
+            const DTransformed& x = xforms[(size_t)index];
+            kind = x.child_kind;
+            index = x.child_index;
+        }
+        nodes[i].pad = kind == RT_SHAPE_MESH ? 1 : 0;
+        if (nodes[i].pad) walk_nodes.push_back((int32_t)i);
+    }
+    sc->nodes = nodes;
     DScene proto{};
+    proto.n_walk_nodes = (int32_t)walk_nodes.size();
     proto.n_nodes = (int32_t)d->n_nodes;
     proto.n_lights = (int32_t)d->n_lights;
     proto.stack_pairs = stack_pairs;
@@ -451,7 +468,6 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         }
         for (int k = 0; k < 3; k++) { proto.walk_box[k] = lo[k]; proto.walk_box[3 + k] = hi[k]; }
         proto.walk_classes = (any && d->n_meshes > 0 && !sc->mesh_only && std::getenv("RT_NO_RAY_CLASSES") == nullptr) ? 1 : 0;
-        proto.pad = 0;
     }
     // One host build, one upload per device: every device of rt_init gets the same arrays.
     for (size_t r = 0; r < g_devices.size(); r++) {
@@ -478,6 +494,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         HIP_TRY(rep->mem.upload(meshes, &dev.meshes));
         HIP_TRY(rep->mem.upload(ref_nodes, &dev.ref_nodes));
         HIP_TRY(rep->mem.upload(fast_nodes, &dev.fast_nodes));
+        HIP_TRY(rep->mem.upload(q_nodes, &dev.q_nodes));
         HIP_TRY(rep->mem.upload(prim_pos, &dev.prim_pos));
         HIP_TRY(rep->mem.upload(prim_tri32, &dev.prim_tri32));
         HIP_TRY(rep->mem.upload(prim_face, &dev.prim_face));
@@ -487,6 +504,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         HIP_TRY(rep->mem.upload(images, &dev.images));
         HIP_TRY(rep->mem.upload(lights, &dev.lights));
         HIP_TRY(rep->mem.upload(node_box, &dev.node_box));
+        HIP_TRY(rep->mem.upload(walk_nodes, &dev.walk_nodes));
         HIP_TRY(hipEventCreateWithFlags(&rep->done, hipEventDisableTiming));
         if (r > 0) HIP_TRY(hipStreamCreateWithFlags(&rep->stream, hipStreamNonBlocking));
         sc->replicas.push_back(std::move(rep));

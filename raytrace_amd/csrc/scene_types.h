@@ -63,6 +63,7 @@ struct DMesh {
     float radius;  // largest |coordinate| in the mesh frame (error bound of the float32 face pre-test)
     int32_t n_faces;
     int32_t pad2;
+    float grid_lo[3], grid_step[3];  // the grid of this mesh's QNodes (mesh frame)
 };
 
 struct DImage {
@@ -80,6 +81,7 @@ struct DScene {
     const DMesh* meshes;
     const RefNode* ref_nodes;
     const FastNode* fast_nodes;
+    const QNode* q_nodes;      // the same trees, quantised: index for index fast_nodes
     const double* prim_pos;    // 9 per prim, leaf order
     const Tri32* prim_tri32;   // leaf order
     const int32_t* prim_face;  // leaf order -> face index within its mesh
@@ -97,7 +99,10 @@ struct DScene {
     // either rays that walk a tree or rays that do not, instead of a few walkers per wave.
     double walk_box[6];
     int32_t walk_classes;  // 1: the ray queues have kRayStripes stripes, the upper half for the rays that reach walk_box
-    int32_t pad;
+    // The nodes whose shape is a mesh, directly or under transforms, in node order: the scattered-ray kernel tests every
+    // other node when it fetches a ray and then walks these trees one after the other, resumably.
+    int32_t n_walk_nodes;
+    const int32_t* walk_nodes;
 };
 
 struct DCamera {
@@ -140,6 +145,20 @@ struct SurfQ {
 };
 constexpr size_t kSurfBytes = 12 * 8 + 4 * 4;
 
+// Closest hits of the generation of rays being traced, written by k_primary / k_walk and shaded by k_shade.  A record
+// names the ray (its slot in the ray queue), the node, the distance and, for a mesh, the face (position in leaf order).
+// Everything else about the hit (barycentrics, point, normal, texture coordinates) is computed by k_shade, which
+// intersects that one face or shape again, limited to the recorded distance: the same arithmetic on the same inputs.
+struct HitQ {
+    uint32_t* ray;   // slot in rays[in]; kNoRay = unused entry of a claimed block
+    int32_t* node;
+    int32_t* leaf;   // mesh: position of the face in leaf order; other shapes: -1
+    double* t;
+};
+constexpr size_t kHitBytes = 8 + 3 * 4;
+constexpr uint32_t kNoRay = 0xffffffffu;
+constexpr uint32_t kClaim = 256;  // queue entries a wave of k_walk reserves at a time (rays to trace, hit records to write)
+
 // An atomic on one address is performed at the memory side (the L2s of the XCDs are not coherent with each other)
 // and only some tens of millions of them finish per second: every wave of a launch adding to the same counter is
 // what bounds the launch.  So the statistics are kept in kTallyStripes copies, each in a 128-byte line of its own
@@ -160,9 +179,12 @@ struct Counters {
     struct alignas(128) Cursor {
         unsigned int v;
     };
-    Cursor next_cursor[kRayStripes];           // append cursors of the next generation's rays, one per stripe (first of the cursors the host resets)
+    Cursor errors;                             // what must never happen, counted: a traversal stack or a hit stripe running full (kept with the statistics: the host checks it whenever it reads them)
+    Cursor ray_cursor[2][kRayStripes];         // append cursors of the two ray queues, one per stripe (first of the cursors the host resets)
     Cursor surf_cursor[kQueueStripes];         // append cursors of the lit surface points
     Cursor tile_cursor[8];                     // next tile of each XCD's share of a primary launch
+    Cursor in_cursor[kRayStripes];             // k_walk: next unclaimed ray of each stripe of the generation being traced
+    Cursor hit_cursor[kQueueStripes];          // k_walk: append cursors of the hit records, one per stripe
 };
 
 }  // namespace rt

@@ -5,16 +5,50 @@ only build `phys.Scene` values.  Where the reference example is an empty stub
 (example/cornell/main.go:4-6, example/teapot/main.go:4-6) or needs an asset that
 is not in the tree (the einstein scan, texture PNGs), the scene is defined here
 with synthetic, seeded inputs of the same shape; every such substitution is
-stated in the function's docstring.
+stated in the function's docstring.  The reference's own data files (teapot.obj, the
+PNG textures of example/material and example/charuco, the PAL257 LED table) are used
+where they exist: copies live in raytrace_amd/assets.
 """
 from __future__ import annotations
 
+import gzip
+import json
 import math
+import os
 
 import numpy as np
 
 from . import phys
 from .phys import MM, M
+
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def asset_bytes(name: str) -> bytes:
+    """A data file of the reference kept under raytrace_amd/assets (tools/make_asset_fixtures.py says which is which)."""
+    with open(os.path.join(ASSETS, name), "rb") as f:
+        data = f.read()
+    return gzip.decompress(data) if name.endswith(".gz") else data
+
+
+def asset_image(name: str) -> np.ndarray:
+    from . import obj
+    return obj.decode_png(asset_bytes(name))
+
+
+def teapot_faces() -> np.ndarray:
+    """The faces of the reference's asset/teapot.obj (3644 vertices, 6320 triangles, no vt / vn, raw units: about
+    [-3, 3.43] x [0, 3.15] x [-2, 2]) as ConvertObjectToShape builds them (node.go:195-232): (n, 3, 5) float64, uv = 0."""
+    from . import obj
+    parsed = obj.ParseFS(obj.MapFS({"teapot.obj": asset_bytes("teapot.obj.gz")}), "teapot.obj")
+    return phys.ConvertObjectToShape(parsed).Face
+
+
+def pal257_led_positions() -> np.ndarray:
+    """(257, 2) LED positions in mm from the centre of the PAL257 emitter (example/gem/led.go:16-273)."""
+    leds = json.loads(asset_bytes("pal257_leds.json"))["leds"]
+    return np.array([(d["x_mm"], d["y_mm"]) for d in leds], dtype=np.float64)
 
 
 # ---- props (phys/prop.go) -----------------------------------------------------------
@@ -145,77 +179,6 @@ def procedural_texture(size: int = 4096, seed: int = 5678) -> np.ndarray:
     return img
 
 
-def lathe_teapot(n_seg: int = 52, seed: int = 7) -> np.ndarray:
-    """Synthetic teapot-like mesh (lathed body + lid knob + torus handle + spout tube),
-    ~6.3 k faces, raw units with the body about 3 wide and 3 tall on y = 0 -- the
-    size class of the reference's asset/teapot.obj (6,320 faces, bbox about
-    [-3,3.4] x [0,3.15] x [-2,2]), which is not copied into this repository."""
-    del seed
-    prof = np.array([[0.0, 0.0], [1.2, 0.0], [1.5, 0.15], [1.9, 0.7], [2.0, 1.2], [1.85, 1.8], [1.5, 2.25], [1.3, 2.4],
-                     [1.35, 2.5], [0.9, 2.7], [0.3, 2.85], [0.25, 3.0], [0.35, 3.1], [0.0, 3.15]])
-    # densify profile
-    pts = []
-    for a, b in zip(prof[:-1], prof[1:]):
-        for t in np.linspace(0, 1, 4, endpoint=False):
-            pts.append(a * (1 - t) + b * t)
-    pts.append(prof[-1])
-    prof = np.array(pts)
-    ang = np.linspace(0, 2 * math.pi, n_seg, endpoint=False)
-    verts, uvs, tris = [], [], []
-    nr = len(prof)
-    for i, (r, h) in enumerate(prof):
-        for j, a in enumerate(ang):
-            verts.append((r * math.cos(a), h, r * math.sin(a)))
-            uvs.append((j / n_seg, i / (nr - 1)))
-    for i in range(nr - 1):
-        for j in range(n_seg):
-            a, b = i * n_seg + j, i * n_seg + (j + 1) % n_seg
-            c, d = a + n_seg, b + n_seg
-            tris.append((a, c, b))
-            tris.append((b, c, d))
-
-    def tube(center_fn, radius, n_len, n_ring):
-        base = len(verts)
-        for i in range(n_len + 1):
-            c, t = center_fn(i / n_len)
-            t = t / np.linalg.norm(t)
-            up = np.array([0.0, 0.0, 1.0])
-            n1 = np.cross(t, up)
-            n1 /= np.linalg.norm(n1)
-            for j in range(n_ring):
-                a = 2 * math.pi * j / n_ring
-                p = c + radius * (math.cos(a) * n1 + math.sin(a) * up)
-                verts.append(tuple(p))
-                uvs.append((i / n_len, j / n_ring))
-        for i in range(n_len):
-            for j in range(n_ring):
-                a = base + i * n_ring + j
-                b = base + i * n_ring + (j + 1) % n_ring
-                tris.append((a, a + n_ring, b))
-                tris.append((b, a + n_ring, b + n_ring))
-
-    def handle(t):
-        a = -0.5 * math.pi + t * math.pi
-        c = np.array([-1.9 - 0.9 * math.cos(a), 1.5 + 0.8 * math.sin(a), 0.0])
-        d = np.array([0.9 * math.sin(a), 0.8 * math.cos(a), 0.0])
-        return c, d
-
-    def spout(t):
-        c = np.array([1.7 + 1.6 * t, 1.0 + 1.4 * t * t + 0.3 * t, 0.0])
-        d = np.array([1.6, 2.8 * t + 0.3, 0.0])
-        return c, d
-
-    tube(handle, 0.16, 18, 10)
-    tube(spout, 0.22, 14, 10)
-    v = np.array(verts)
-    f = np.array(tris, dtype=np.int64)
-    # drop degenerate faces (profile points on the axis)
-    p = v[f]
-    area = np.linalg.norm(np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), axis=1)
-    f = f[area > 1e-9]
-    return faces_from(v, np.array(uvs), f)
-
-
 # ---- configurations -----------------------------------------------------------------------
 
 
@@ -252,10 +215,10 @@ def cornell(dx=256, dy=256, spp=64, depth=5, seed=0) -> phys.Scene:
 
 
 def teapot(dx=1920, dy=1080, spp=256, depth=6, seed=0, aperture=0.0) -> phys.Scene:
-    """Teapot config (the reference example is an empty stub): a ~6.3 k face lathed
-    teapot mesh (synthetic, see lathe_teapot) scaled x10 mm, Metal{0.9, Fuzz 0.05}, on a
-    400 mm Lambertian checkerboard quad, two point lights, FocusableCamera."""
-    faces = lathe_teapot()
+    """Teapot config (the reference example is an empty stub): the reference's asset/teapot.obj
+    (6320 faces) scaled x10 mm, Metal{0.9, Fuzz 0.05}, on a 400 mm Lambertian checkerboard quad,
+    two point lights, FocusableCamera."""
+    faces = teapot_faces().copy()
     faces[:, :, :3] *= 10.0 * MM
     mesh = phys.NewMesh(faces)
     checker = phys.TextureCheckerboard(Odd=phys.TextureUniform((0.2, 0.5, 0.6)), Even=phys.TextureUniform((0.9, 0.9, 0.9)),
@@ -324,11 +287,11 @@ def write_obj(faces: np.ndarray, mtl_name="scan.mtl", material="scan", texture="
     return "\n".join(lines) + "\n", f"newmtl {material}\nKd 1 1 1\nmap_Kd {texture}\n"
 
 
-def material(dx=2048, dy=2048, spp=4096, depth=5, seed=0, tex_size=(564, 568)) -> phys.Scene:
+def material(dx=2048, dy=2048, spp=4096, depth=5, seed=0, tex_size=None) -> phys.Scene:
     """example/material/main.go:29-123: the sphere grid of Lambertian / Dielectric / Metal /
     debug materials, three axis cylinders, orthographic camera with VUp = X, one point
-    light.  The two PNG textures of the example are replaced by procedural images of the
-    same sizes (texture.png 568x564, faces.png 730x726)."""
+    light, with the example's own texture.png (568x564) and faces.png (730x726).  tex_size=None
+    (default) uses them; a (rows, columns) pair swaps in procedural images of that size."""
 
     def node(col, row, name, mat):  # main.go:15-26
         cx = col * 10.0 * MM - 45.0 * MM
@@ -338,8 +301,11 @@ def material(dx=2048, dy=2048, spp=4096, depth=5, seed=0, tex_size=(564, 568)) -
     def lam(c):
         return phys.Lambertian(phys.TextureUniform(c))
 
-    tex_a = procedural_texture(max(tex_size), 11)[:tex_size[0], :tex_size[1]].copy()
-    tex_b = procedural_texture(730, 12)[:726, :730].copy()
+    if tex_size is None:
+        tex_a, tex_b = asset_image("texture.png"), asset_image("faces.png")
+    else:
+        tex_a = procedural_texture(max(tex_size), 11)[:tex_size[0], :tex_size[1]].copy()
+        tex_b = procedural_texture(730, 12)[:726, :730].copy()
     nodes = [
         node(0, 0, "checker red white", phys.Lambertian(phys.TextureCheckerboard(
             phys.TextureUniform((0.2, 0.5, 0.6)), phys.TextureUniform((0.5, 0.0, 0.0)), 5.0))),
@@ -376,48 +342,14 @@ def material(dx=2048, dy=2048, spp=4096, depth=5, seed=0, tex_size=(564, 568)) -
                       RenderOptions=phys.RenderOptions(seed, spp, depth, dx, dy))
 
 
-def charuco_board_image(size: int = 1772, squares: int = 7, seed: int = 4242) -> np.ndarray:
-    """Stand-in for example/charuco/asset/Square150MM.png (1772x1772): a chessboard whose white squares
-    carry a random 6x6 bit marker, RGBA8."""
-    rng = np.random.default_rng(seed)
-    img = np.full((size, size, 4), 255, dtype=np.uint8)
-    sq = size // squares
-    for r in range(squares):
-        for c in range(squares):
-            y0, x0 = r * sq, c * sq
-            if (r + c) % 2 == 0:
-                img[y0:y0 + sq, x0:x0 + sq, :3] = 0
-            else:
-                cell = sq // 8
-                bits = rng.integers(0, 2, size=(6, 6))
-                for i in range(6):
-                    for j in range(6):
-                        if bits[i, j]:
-                            img[y0 + (i + 1) * cell:y0 + (i + 2) * cell, x0 + (j + 1) * cell:x0 + (j + 2) * cell, :3] = 0
-    return img
-
-
-def led_ring_positions(n: int = 257, outer_mm: float = 43.4) -> np.ndarray:
-    """Stand-in for the LED table of example/gem/led.go (PAL257: 257 emitters on 8 concentric rings, outer
-    radius 43.4 mm): one centre LED and rings of 8, 16, ... LEDs whose counts add up to n."""
-    counts = [8, 16, 24, 32, 40, 44, 44, 48]
-    assert 1 + sum(counts) == n
-    pts = [(0.0, 0.0)]
-    for k, c in enumerate(counts, start=1):
-        rad = outer_mm * k / len(counts)
-        for i in range(c):
-            a = 2.0 * math.pi * (i + 0.5 * (k % 2)) / c
-            pts.append((rad * math.cos(a), rad * math.sin(a)))
-    return np.array(pts)
-
-
 def charuco(dx=1440, dy=1080, spp=16, depth=6, seed=0, frame=0, frames_per_orbit=240, leds=False) -> phys.Scene:
     """example/charuco/main.go:36-289: emitter spheres on the corners of a 150 mm box, three axis cylinders,
     twelve cylinder rods along the box edges, a 150 mm quad with an image texture (default nearest
     sampling), CalibratedCamera{IntrinsicsFireflyDLGeneric6mm} on an orbit of radius 400 mm at height 320 mm
-    with VUp = -Z, one point light.  frame selects the orbit position (theta = 2 pi frame / frames_per_orbit).
+    with VUp = -Z, one point light.  The board is the example's own asset/Square150MM.png (1772x1772).
+    frame selects the orbit position (theta = 2 pi frame / frames_per_orbit).
     leds=True adds the light-loop stress case: a Lambertian ground quad under 257 point lights
-    (I = 0.3 / 257 each) placed 100 mm above it on the rings of led_ring_positions()."""
+    (I = 0.3 / 257 each) placed 100 mm above it at the LED positions of example/gem/led.go (PAL257)."""
     W = H = D = 150.0 * MM
     colormap0 = (0.5, 0.5, 0.5)
     P = (203.0 / 255.0, 136.0 / 255.0, 206.0 / 255.0)
@@ -445,14 +377,14 @@ def charuco(dx=1440, dy=1080, spp=16, depth=6, seed=0, frame=0, frames_per_orbit
         rod("AxisZ1Bottom", cz_, (-W / 2, -H / 2, 0.0), Z, D), rod("AxisZ2Bottom", cz_, (W / 2, -H / 2, 0.0), Z, D),
         rod("AxisY1Bottom", cy_, (-W / 2, -H / 2, 0.0), Y, H), rod("AxisY2Bottom", cy_, (W / 2, -H / 2, 0.0), Y, H),
         phys.Node("CharucoSquare150MM", phys.Quad((0.0, 0.0, 0.0), Z, 150.0 * MM, 150.0 * MM),
-                  phys.Emitter(phys.TextureImage(charuco_board_image(), "", ""))),
+                  phys.Emitter(phys.TextureImage(asset_image("Square150MM.png"), "", ""))),
     ]
     lights = [phys.PointLight((500.0 * MM, 500.0 * MM, 500.0 * MM), (0.3, 0.3, 0.3))]
     if leds:
         nodes.append(phys.Node("LedGround", phys.Quad((0.0, 0.0, -2.0 * MM), Z, 400.0 * MM, 400.0 * MM),
                                phys.Lambertian(phys.TextureUniform((0.8, 0.8, 0.8)))))
         each = 0.3 / 257.0
-        lights = [phys.PointLight((x * MM, y * MM, 100.0 * MM), (each, each, each)) for x, y in led_ring_positions()]
+        lights = [phys.PointLight((x * MM, y * MM, 100.0 * MM), (each, each, each)) for x, y in pal257_led_positions()]
     theta = 2.0 * math.pi * (frame % frames_per_orbit) / frames_per_orbit
     cam = phys.CalibratedCamera(
         Intrinsics=phys.IntrinsicsFireflyDLGeneric6mm,
