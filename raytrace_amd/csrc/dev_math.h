@@ -78,10 +78,18 @@ RT_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 
 struct Rng {
     uint32_t k0, k1, pixel, sample, path, n;
+    // A Philox block is 128 bits = two draws: draw n is half n & 1 of the block with counter word n >> 1.  The block of
+    // the last draw is kept, so two consecutive draws cost one block (the stream is the same either way).
+    uint32_t have = 0xffffffffu;  // counter word of the block in `blk`
+    uint32_t blk[4];
     RT_HD double float64() {  // uniform in [0,1), 53 bits, like math/rand's Float64
-        uint32_t c[4] = {pixel, sample, path, n >> 1};
-        philox4x32_10(c, k0, k1);
-        uint64_t bits = (n & 1) ? ((uint64_t)c[3] << 32 | c[2]) : ((uint64_t)c[1] << 32 | c[0]);
+        const uint32_t word = n >> 1;
+        if (word != have) {
+            blk[0] = pixel; blk[1] = sample; blk[2] = path; blk[3] = word;
+            philox4x32_10(blk, k0, k1);
+            have = word;
+        }
+        const uint64_t bits = (n & 1) ? ((uint64_t)blk[3] << 32 | blk[2]) : ((uint64_t)blk[1] << 32 | blk[0]);
         n++;
         return (double)(bits >> 11) * 0x1.0p-53;
     }
