@@ -373,6 +373,48 @@ int rt_intersect_batch(rt_scene* scene, const double* o, const double* d, uint64
 int rt_cast_batch(const rt_camera_desc* camera, const double* st, const uint32_t* pixel_sample,
                   uint64_t n, int64_t seed, double* o_out, double* d_out);
 
+/* ---- validation entry points for materials --------------------------------------------------
+ * MicrofacetBRDF.D / G1 / G / F / Evaluate (phys/microfacet.go:28-103) evaluated on the device for n
+ * argument sets, so that the reference's own tables (microfacet_test.go:12-443) can be run against
+ * the functions the render kernels call.  args holds 4 vectors per set (12 float64), in the order
+ * of the Go signatures; a function ignores the ones it does not take.  roughness: n values; f0:
+ * n x 3; out: n x 3 (a scalar result in out[3 i]).  All host arrays. */
+enum rt_microfacet_fn {
+    RT_MF_D = 0,        /* D(h, n)              args: h, n          microfacet.go:28-39 */
+    RT_MF_G1 = 1,       /* G1(v, n, h)          args: v, n, h       microfacet.go:44-62 */
+    RT_MF_G = 2,        /* G(wo, wi, n, h)      args: wo, wi, n, h  microfacet.go:66-68 */
+    RT_MF_F = 3,        /* F(wo, h)             args: wo, h         microfacet.go:73-78 */
+    RT_MF_EVALUATE = 4  /* Evaluate(wo, wi, n)  args: wo, wi, n     microfacet.go:83-103 */
+};
+int rt_microfacet_batch(int which, uint64_t n, const double* roughness, const double* f0, const double* args, double* out);
+
+/* Material.Resolve and Material.ComputeDirectLighting (material.go:28-32; material_lambertian.go:18-81,
+ * material_metal.go:28-108, material_dielectric.go:29-172, material_emitter.go:22-30,
+ * material_debug_uv.go:18-32, material_debug_normal.go:45-91) for n explicit hits: exactly what the
+ * render kernels compute for a queued hit, returned instead of queued.  An rt_shade_in is a
+ * surfaceInteraction (material.go:14-19): the incoming ray's direction and radiance, the collision,
+ * the node that was hit (its shape is the one the shadow rays skip) and the material to apply, plus
+ * the position on the random stream (pixel, sample, path-tree index, draws made so far). */
+typedef struct rt_shade_in {
+    int32_t material; /* index into rt_scene_desc.materials */
+    int32_t node;     /* the node hit: skipped by the occlusion test (material_lambertian.go:37) */
+    double d[3];        /* incoming.direction */
+    double radiance[3]; /* incoming.radiance  */
+    double t, at[3], normal[3], uv[2]; /* collision (shape.go:11-16) */
+    uint32_t pixel, sample, path, draws;
+} rt_shade_in;
+typedef struct rt_shade_out {
+    double emission[3];  /* resolution.emission */
+    double dir[2][3];    /* resolution.scattered[k].direction (their origin is the hit point) */
+    double rad[2][3];    /* resolution.scattered[k].radiance */
+    double direct[3];    /* ComputeDirectLighting */
+    int32_t n_children;  /* len(resolution.scattered) */
+    uint32_t draws_after; /* draws made on the stream once Resolve returned */
+    uint32_t shadow_rays; /* occlusion rays cast */
+    uint32_t reserved;
+} rt_shade_out;
+int rt_shade_batch(rt_scene* scene, const rt_shade_in* hits, uint64_t n, int64_t seed, int mode, rt_shade_out* out);
+
 /* Reconstruction filters of phys/reconstruct.go:28-87 (1-D, even, compact support). */
 enum rt_recon_filter {
     RT_RECON_BOX = 0,     /* BoxFilter:  radius 0.5, w = 1 for |x| < 0.5              reconstruct.go:31-43 */

@@ -47,6 +47,7 @@ def load():
         lib.oracle_render.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), P(C.c_uint8), C.c_size_t,
                                       P(abi.Stats), P(RenderExtra)]
         lib.oracle_microfacet.argtypes = [C.c_int, C.c_double] + [P(C.c_double)] * 6
+        lib.oracle_shade_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]
         lib.oracle_r3.argtypes = [C.c_int, P(C.c_double), P(C.c_double), C.c_double, C.c_double, P(C.c_double)]
         lib.oracle_aabb_intersects.argtypes = [P(C.c_double)] * 4
         lib.oracle_aabb_hit.argtypes = [P(C.c_double)] * 4 + [C.c_double, C.c_double]
@@ -114,6 +115,12 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError(f"oracle_render: {self.lib.oracle_last_error().decode()}")
         return img, st, ex, film
+
+    def shade(self, hits, seed=0):
+        h = np.ascontiguousarray(hits, dtype=abi.SHADE_IN_DTYPE)
+        out = np.zeros(len(h), dtype=abi.SHADE_OUT_DTYPE)
+        assert self.lib.oracle_shade_batch(self.handle, h.ctypes.data, len(h), int(seed), out.ctypes.data) == 0
+        return out
 
     def bvh_info(self, mesh_index=0):
         info = abi.BvhInfo()

@@ -1489,6 +1489,49 @@ int oracle_microfacet(int which, double roughness, const double* f0, const doubl
     return RT_ERR_INVALID;
 }
 
+// Material.Resolve + ComputeDirectLighting for explicit hits (the checker of rt_shade_batch): the reference's own two
+// calls, tracePath's lines render.go:174-176, on a surfaceInteraction built from the record.
+int oracle_shade_batch(const oracle_scene* s, const rt_shade_in* in, uint64_t n, int64_t seed, rt_shade_out* out) {
+    const Scene& sc = *reinterpret_cast<const Scene*>(s);
+    for (uint64_t i = 0; i < n; i++) {
+        const rt_shade_in& h = in[i];
+        if (h.material < 0 || (size_t)h.material >= sc.materials.size() || h.node < 0 || (size_t)h.node >= sc.nodes.size()) return RT_ERR_INVALID;
+        Interaction si;
+        si.incoming.direction = v3(h.d);
+        si.incoming.radiance = v3(h.radiance);
+        si.incoming.origin = sub(v3(h.at), muls(v3(h.d), h.t));
+        si.incoming.rng.k0 = (uint32_t)((uint64_t)seed & 0xffffffffu);
+        si.incoming.rng.k1 = (uint32_t)((uint64_t)seed >> 32);
+        si.incoming.rng.pixel = h.pixel;
+        si.incoming.rng.sample = h.sample;
+        si.incoming.rng.path = h.path;
+        si.incoming.rng.n = h.draws;
+        si.outgoing = muls(si.incoming.direction, -1);
+        si.collision.t = h.t;
+        si.collision.at = v3(h.at);
+        si.collision.normal = v3(h.normal);
+        si.collision.uv = V2{h.uv[0], h.uv[1]};
+        si.node = h.node;
+        const Material& m = sc.materials[(size_t)h.material];
+        Resolution res = resolve(m, si);
+        Stats st;
+        const V3 direct = direct_lighting(sc, m, si, st);
+        rt_shade_out& o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        o.emission[0] = res.emission.x; o.emission[1] = res.emission.y; o.emission[2] = res.emission.z;
+        o.n_children = res.n_scattered;
+        o.draws_after = si.incoming.rng.n;
+        for (int k = 0; k < res.n_scattered; k++) {
+            const Ray& c = res.scattered[k];
+            o.dir[k][0] = c.direction.x; o.dir[k][1] = c.direction.y; o.dir[k][2] = c.direction.z;
+            o.rad[k][0] = c.radiance.x; o.rad[k][1] = c.radiance.y; o.rad[k][2] = c.radiance.z;
+        }
+        o.direct[0] = direct.x; o.direct[1] = direct.y; o.direct[2] = direct.z;
+        o.shadow_rays = (uint32_t)st.shadow;
+    }
+    return RT_OK;
+}
+
 // r3 operations: op = 0 add, 1 sub, 2 mul, 3 muls(s), 4 divs(s), 5 dot -> out[0], 6 cross, 7 length -> out[0], 8 unit,
 // 9 lerp(s), 10 clip(s, t)
 int oracle_r3(int op, const double* a, const double* b, double s, double t, double* out) {

@@ -11,7 +11,7 @@ _PATH = os.environ.get("RT_LIB_PATH") or os.path.join(os.path.dirname(os.path.ab
 SYMBOLS = [
     "rt_apply_filter", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
     "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info", "rt_obj_scan_text", "rt_obj_scan_free",
-    "rt_bvh_build", "rt_render_film_noalloc",
+    "rt_bvh_build", "rt_render_film_noalloc", "rt_microfacet_batch", "rt_shade_batch",
 ]
 
 
@@ -60,6 +60,10 @@ def open_library() -> C.CDLL:
     lib.rt_cast_batch.argtypes = [P(abi.CameraDesc), P(C.c_double), P(C.c_uint32), C.c_uint64, C.c_int64, P(C.c_double),
                                   P(C.c_double)]
     lib.rt_cast_batch.restype = C.c_int
+    lib.rt_microfacet_batch.argtypes = [C.c_int, C.c_uint64, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double)]
+    lib.rt_microfacet_batch.restype = C.c_int
+    lib.rt_shade_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_void_p]
+    lib.rt_shade_batch.restype = C.c_int
     lib.rt_apply_filter.argtypes = [P(C.c_uint8), C.c_size_t, C.c_int32, C.c_int32, C.c_int, P(C.c_uint8), C.c_size_t]
     lib.rt_apply_filter.restype = C.c_int
     lib.rt_scene_bvh_info.argtypes = [C.c_void_p, C.c_uint64, P(abi.BvhInfo)]

@@ -179,3 +179,21 @@ class ObjScan(C.Structure):  # rt_obj_scan
 
 
 OBJ_USEMTL, OBJ_MTLLIB = 0, 1
+
+
+class ShadeIn(C.Structure):  # rt_shade_in
+    _fields_ = [("material", C.c_int32), ("node", C.c_int32), ("d", D3), ("radiance", D3), ("t", C.c_double), ("at", D3),
+                ("normal", D3), ("uv", C.c_double * 2), ("pixel", C.c_uint32), ("sample", C.c_uint32), ("path", C.c_uint32),
+                ("draws", C.c_uint32)]
+
+
+class ShadeOut(C.Structure):  # rt_shade_out
+    _fields_ = [("emission", D3), ("dir", D3 * 2), ("rad", D3 * 2), ("direct", D3), ("n_children", C.c_int32),
+                ("draws_after", C.c_uint32), ("shadow_rays", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+SHADE_IN_DTYPE = [("material", "<i4"), ("node", "<i4"), ("d", "<f8", (3,)), ("radiance", "<f8", (3,)), ("t", "<f8"), ("at", "<f8", (3,)),
+                  ("normal", "<f8", (3,)), ("uv", "<f8", (2,)), ("pixel", "<u4"), ("sample", "<u4"), ("path", "<u4"), ("draws", "<u4")]
+SHADE_OUT_DTYPE = [("emission", "<f8", (3,)), ("dir", "<f8", (2, 3)), ("rad", "<f8", (2, 3)), ("direct", "<f8", (3,)),
+                   ("n_children", "<i4"), ("draws_after", "<u4"), ("shadow_rays", "<u4"), ("reserved", "<u4")]
+MF_D, MF_G1, MF_G, MF_F, MF_EVALUATE = range(5)  # rt_microfacet_fn

@@ -94,14 +94,20 @@ RT_DEV double mf_G1(double roughness, V3 v, V3 n, V3 h) {
     if (a >= 1.6) return 1;
     return (3.535 * a + 2.181 * a * a) / (1 + 2.276 * a + 2.577 * a * a);
 }
-RT_DEV V3 mf_evaluate(double roughness, V3 f0, V3 wo, V3 wi, V3 n) {
+RT_DEV double mf_G(double roughness, V3 wo, V3 wi, V3 n, V3 h) {  // microfacet.go:66-68
+    return mf_G1(roughness, wo, n, h) * mf_G1(roughness, wi, n, h);
+}
+RT_DEV V3 mf_F(V3 f0, V3 wo, V3 h) {  // microfacet.go:73-78
+    double ct = go_max(0, dot(h, wo));
+    double p5 = pow(1 - ct, 5.0);
+    return f0 + (mk(1, 1, 1) - f0) * p5;
+}
+RT_DEV V3 mf_evaluate(double roughness, V3 f0, V3 wo, V3 wi, V3 n) {  // microfacet.go:83-103
     wo = unit(wo); wi = unit(wi); n = unit(n);
     V3 h = unit(wo + wi);
     double D = mf_D(roughness, h, n);
-    double G = mf_G1(roughness, wo, n, h) * mf_G1(roughness, wi, n, h);
-    double ct = go_max(0, dot(h, wo));
-    double p5 = pow(1 - ct, 5.0);
-    V3 F = f0 + (mk(1, 1, 1) - f0) * p5;
+    double G = mf_G(roughness, wo, wi, n, h);
+    V3 F = mf_F(f0, wo, h);
     double denom = 4 * go_max(0, dot(n, wo)) * go_max(0, dot(n, wi)) + kEps;
     return F * (D * G / denom);
 }
@@ -121,6 +127,54 @@ RT_DEV bool refract(V3 v, V3 n, double ni_over_nt, V3& out) {  // material_diele
         return true;
     }
     return false;
+}
+
+// What ComputeDirectLighting needs of a hit once Material.Resolve is done (material_lambertian.go:18-33,
+// material_metal.go:56-67, material_dielectric.go:105-127): the shading normal (flipped when a dielectric is hit
+// from inside), the unit direction back along the ray, and the Lambertian albedo / Metal colour.
+struct LitSurface {
+    V3 n, wo, albedo;
+    int inside;
+};
+RT_DEV LitSurface lit_surface(const rt_material& m, V3 normal, V3 d, V3 lambert_albedo) {
+    LitSurface s;
+    s.n = unit(normal);
+    s.wo = unit(d * -1.0);  // s.outgoing.Unit() (material_metal.go:59)
+    s.albedo = mk(0, 0, 0);
+    s.inside = 0;
+    if (m.kind == RT_MAT_LAMBERTIAN) s.albedo = lambert_albedo;  // Material.Resolve has just evaluated the texture here
+    else if (m.kind == RT_MAT_METAL) s.albedo = ld3(m.albedo);
+    else if (!(dot(s.wo, s.n) > 0)) { s.inside = 1; s.n = s.n * -1.0; }  // material_dielectric.go:112-120
+    return s;
+}
+
+// The shadow ray towards a point light (light.go:29-35 and the loop heads of ComputeDirectLighting).
+RT_DEV Ray shadow_ray(const rt_material& m, const rt_light& L, V3 p, V3 n, V3& dir, double& dist) {
+    dir = ld3(L.position) - p;
+    dist = length(dir);
+    dir = dir / dist;
+    const V3 wi = m.kind == RT_MAT_LAMBERTIAN ? dir : unit(dir);
+    return Ray{p + n * kEps, wi};
+}
+
+// One unoccluded light's contribution (material_lambertian.go:47-52, material_metal.go:95-106, material_dielectric.go:159-170).
+RT_DEV V3 light_contribution(const rt_material& m, const rt_light& L, V3 n, V3 wo, V3 albedo, int inside, V3 dir, V3 wi) {
+    if (m.kind == RT_MAT_LAMBERTIAN) {
+        const double ndl = go_max(0, dot(n, dir));
+        return (albedo * ld3(L.intensity)) * ndl;
+    }
+    if (m.kind == RT_MAT_METAL) {
+        const V3 val = mf_evaluate(m.fuzz, ld3(m.albedo), wo, wi, n);
+        const double ct = go_max(0, dot(n, wi));
+        return (ld3(L.intensity) * val) * ct;
+    }
+    double eta_i = m.ior_exterior, eta_t = m.ior_interior;
+    if (inside) { const double tmp = eta_i; eta_i = eta_t; eta_t = tmp; }
+    const double cos_i = go_max(0, dot(wi, n));
+    const double fresnel = reflectance(cos_i, eta_i, eta_t);
+    const V3 val = mf_evaluate(m.roughness, mk(1, 1, 1), wo, wi, n) * fresnel;
+    const double ct = go_max(0, dot(n, wi));
+    return (ld3(L.intensity) * val) * ct;
 }
 
 struct Scatter {

@@ -84,6 +84,7 @@ struct rt_scene {
     // host copies of what the screen-space occupancy map of a camera is made from
     std::vector<double> node_box;        // DScene::node_box, 6 per node
     std::vector<rt::DNode> nodes;
+    size_t n_materials = 0;
     std::vector<rt::DMesh> meshes;
     std::vector<rt::FastNode> fast_nodes;
     std::atomic<bool> cancel{false};

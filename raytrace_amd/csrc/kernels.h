@@ -84,6 +84,8 @@ void debug_trace_stats(unsigned long long* out32, bool reset);
 void launch_filter(const uint8_t* src, int32_t w, int32_t h, int filter, double* tmp, uint8_t* dst, hipStream_t s);
 void launch_intersect_batch(const DScene& sc, const double* o, const double* d, uint64_t n, double tmin, double tmax, int mode,
                             rt_hit* hits, hipStream_t s);
+void launch_microfacet_batch(int which, uint64_t n, const double* roughness, const double* f0, const double* args, double* out, hipStream_t s);
+void launch_shade_batch(const DScene& sc, const rt_shade_in* in, uint64_t n, uint32_t seed_lo, uint32_t seed_hi, int mode, rt_shade_out* out, hipStream_t s);
 void launch_cast_batch(const DCamera& cam, const double* st, const uint32_t* pixel_sample, uint64_t n, uint32_t seed_lo,
                        uint32_t seed_hi, double* o, double* d, hipStream_t s);
 

@@ -425,11 +425,11 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
         }
         if (sc.n_lights > 0 && (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC)) {
             want_surf = true;
-            s_n = unit(c.normal);
-            s_wo = unit(r.d * -1.0);  // s.outgoing.Unit() (material_metal.go:59)
-            if (m.kind == RT_MAT_LAMBERTIAN) s_alb = sct.albedo;  // Material.Resolve has just evaluated the texture here
-            else if (m.kind == RT_MAT_METAL) s_alb = ld3(m.albedo);
-            else if (!(dot(s_wo, s_n) > 0)) { inside = 1; s_n = s_n * -1.0; }  // material_dielectric.go:112-120
+            const LitSurface lit = lit_surface(m, c.normal, r.d, sct.albedo);
+            s_n = lit.n;
+            s_wo = lit.wo;
+            s_alb = lit.albedo;
+            inside = lit.inside;
         }
     }
     wave_tally(q.counters, n_counted, 0, n_cut);
@@ -1123,34 +1123,16 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_
         const rt_material m = sc.materials[q.surfs.material[i]];
         const V3 p = mk(q.surfs.p[0][i], q.surfs.p[1][i], q.surfs.p[2][i]);
         const V3 n = mk(q.surfs.n[0][i], q.surfs.n[1][i], q.surfs.n[2][i]);
-        V3 dir = ld3(L.position) - p;  // PointLight.Sample, light.go:29-35
-        const double dist = length(dir);
-        dir = dir / dist;
-        const V3 wi = m.kind == RT_MAT_LAMBERTIAN ? dir : unit(dir);
-        Ray sh{p + n * kEps, wi};
+        V3 dir;
+        double dist;
+        const Ray sh = shadow_ray(m, L, p, n, dir, dist);
         const bool occ = scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc);
         RT_WFLUSH(vc);
-        if (occ) {
-            // in shadow: nothing to add
-        } else if (m.kind == RT_MAT_LAMBERTIAN) {
-            const double ndl = go_max(0, dot(n, dir));
-            const V3 alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
-            contrib = (alb * ld3(L.intensity)) * ndl;
-        } else {
-            const V3 wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
-            if (m.kind == RT_MAT_METAL) {
-                const V3 val = mf_evaluate(m.fuzz, ld3(m.albedo), wo, wi, n);
-                const double ct = go_max(0, dot(n, wi));
-                contrib = (ld3(L.intensity) * val) * ct;
-            } else {
-                double eta_i = m.ior_exterior, eta_t = m.ior_interior;
-                if (q.surfs.inside[i]) { const double tmp = eta_i; eta_i = eta_t; eta_t = tmp; }
-                const double cos_i = go_max(0, dot(wi, n));
-                const double fresnel = reflectance(cos_i, eta_i, eta_t);
-                const V3 val = mf_evaluate(m.roughness, mk(1, 1, 1), wo, wi, n) * fresnel;
-                const double ct = go_max(0, dot(n, wi));
-                contrib = (ld3(L.intensity) * val) * ct;
-            }
+        if (!occ) {
+            V3 wo = mk(0, 0, 0), alb = mk(0, 0, 0);  // only the one the material reads is fetched
+            if (m.kind == RT_MAT_LAMBERTIAN) alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
+            else wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
+            contrib = light_contribution(m, L, n, wo, alb, q.surfs.inside[i], dir, sh.d);
         }
     }
     film_add_wave(film, pixel, contrib);
@@ -1209,6 +1191,72 @@ __global__ void __launch_bounds__(kBlock) k_cast_batch(DCamera cam, const double
     Ray r = camera_cast(cam, st[2 * i], st[2 * i + 1], rng);
     st3(o + 3 * i, r.o);
     st3(d + 3 * i, r.d);
+}
+
+// ---- validation entry points for materials -------------------------------------------------------
+
+// MicrofacetBRDF.D / G1 / G / F / Evaluate (microfacet.go:28-103) for n argument sets.
+__global__ void __launch_bounds__(kBlock) k_microfacet_batch(int which, uint64_t n, const double* __restrict__ roughness, const double* __restrict__ f0,
+                                                            const double* __restrict__ args, double* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const V3 a = ld3(args + 12 * i), b = ld3(args + 12 * i + 3), c = ld3(args + 12 * i + 6), d = ld3(args + 12 * i + 9);
+    const double rough = roughness[i];
+    V3 r = mk(0, 0, 0);
+    switch (which) {
+        case 0: r.x = mf_D(rough, a, b); break;
+        case 1: r.x = mf_G1(rough, a, b, c); break;
+        case 2: r.x = mf_G(rough, a, b, c, d); break;
+        case 3: r = mf_F(ld3(f0 + 3 * i), a, b); break;
+        default: r = mf_evaluate(rough, ld3(f0 + 3 * i), a, b, c); break;
+    }
+    st3(out + 3 * i, r);
+}
+
+// Material.Resolve and ComputeDirectLighting for explicit hits (material_*.go), one thread per hit: what shade_lane and
+// k_direct compute for a queued hit, returned instead of queued.
+template <int MODE>
+__global__ void __launch_bounds__(kTraceBlock, 2) k_shade_batch(DScene sc, const rt_shade_in* __restrict__ in, uint64_t n, uint32_t seed_lo, uint32_t seed_hi,
+                                                               rt_shade_out* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x;
+    if (i >= n) return;
+    const rt_shade_in h = in[i];
+    const rt_material m = sc.materials[h.material];
+    Col c;
+    c.t = h.t;
+    c.at = ld3(h.at);
+    c.normal = ld3(h.normal);
+    c.u = h.uv[0];
+    c.v = h.uv[1];
+    Rng rng{seed_lo, seed_hi, h.pixel, h.sample, h.path, h.draws};
+    Scatter sct;
+    resolve(sc, m, ld3(h.d), ld3(h.radiance), c, rng, sct);
+    rt_shade_out o;
+    st3(o.emission, sct.emission);
+    o.n_children = sct.n;
+    o.draws_after = rng.n;
+    for (int k = 0; k < 2; k++) {
+        st3(o.dir[k], k < sct.n ? sct.dir[k] : mk(0, 0, 0));
+        st3(o.rad[k], k < sct.n ? sct.rad[k] : mk(0, 0, 0));
+    }
+    V3 direct = mk(0, 0, 0);
+    uint32_t shadow = 0;
+    VisitCounts vc{0, 0};
+    if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC) {
+        const LitSurface lit = lit_surface(m, c.normal, ld3(h.d), sct.albedo);
+        for (int l = 0; l < sc.n_lights; l++) {
+            const rt_light L = sc.lights[l];
+            V3 dir;
+            double dist;
+            const Ray sh = shadow_ray(m, L, c.at, lit.n, dir, dist);
+            shadow++;
+            if (scene_occluded<MODE>(sc, sh, dist, h.node, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc)) continue;
+            direct = direct + light_contribution(m, L, lit.n, lit.wo, lit.albedo, lit.inside, dir, sh.d);
+        }
+    }
+    st3(o.direct, direct);
+    o.shadow_rays = shadow;
+    out[i] = o;
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
@@ -1471,6 +1519,19 @@ void launch_intersect_batch(const DScene& sc, const double* o, const double* d, 
     else
         hipLaunchKernelGGL(k_intersect_batch<RT_MODE_FAST>, dim3(trace_blocks(n)), dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, o, d, n, tmin,
                            tmax, hits);
+}
+
+void launch_microfacet_batch(int which, uint64_t n, const double* roughness, const double* f0, const double* args, double* out, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_microfacet_batch, dim3(blocks_for(n)), dim3(kBlock), 0, s, which, n, roughness, f0, args, out);
+}
+
+void launch_shade_batch(const DScene& sc, const rt_shade_in* in, uint64_t n, uint32_t seed_lo, uint32_t seed_hi, int mode, rt_shade_out* out, hipStream_t s) {
+    if (n == 0) return;
+    if (mode == RT_MODE_REFERENCE)
+        hipLaunchKernelGGL(k_shade_batch<RT_MODE_REFERENCE>, dim3(trace_blocks(n)), dim3(kTraceBlock), 0, s, sc, in, n, seed_lo, seed_hi, out);
+    else
+        hipLaunchKernelGGL(k_shade_batch<RT_MODE_FAST>, dim3(trace_blocks(n)), dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, in, n, seed_lo, seed_hi, out);
 }
 
 void launch_cast_batch(const DCamera& cam, const double* st, const uint32_t* pixel_sample, uint64_t n, uint32_t seed_lo,

@@ -428,6 +428,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<rt_texture> textures(d->textures, d->textures + d->n_textures);
     std::vector<rt_light> lights(d->lights, d->lights + d->n_lights);
     sc->node_box = node_box;
+    sc->n_materials = materials.size();
     sc->meshes = meshes;
     sc->fast_nodes = fast_nodes;
     sc->all_terminal = true;
@@ -656,6 +657,51 @@ int rt_intersect_batch(rt_scene* scene, const double* o, const double* d, uint64
     launch_intersect_batch(scene->replicas[0]->dev, od, dd, n, tmin, tmax, mode, hd, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hits, hd, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_microfacet_batch(int which, uint64_t n, const double* roughness, const double* f0, const double* args, double* out) {
+    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    if (which < RT_MF_D || which > RT_MF_EVALUATE) return fail(RT_ERR_INVALID, "unknown microfacet function");
+    if (n && (!roughness || !f0 || !args || !out)) return fail(RT_ERR_INVALID, "null argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(g_devices[0]));
+    DeviceBuffers tmp;
+    double *rd = nullptr, *fd = nullptr, *ad = nullptr, *od = nullptr;
+    HIP_TRY(tmp.alloc(n, &rd));
+    HIP_TRY(tmp.alloc(n * 3, &fd));
+    HIP_TRY(tmp.alloc(n * 12, &ad));
+    HIP_TRY(tmp.alloc(n * 3, &od));
+    HIP_TRY(hipMemcpy(rd, roughness, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(fd, f0, n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ad, args, n * 96, hipMemcpyHostToDevice));
+    launch_microfacet_batch(which, n, rd, fd, ad, od, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, od, n * 24, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_shade_batch(rt_scene* scene, const rt_shade_in* hits, uint64_t n, int64_t seed, int mode, rt_shade_out* out) {
+    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    if (!scene || (n && (!hits || !out))) return fail(RT_ERR_INVALID, "null argument");
+    if (mode != RT_MODE_REFERENCE && mode != RT_MODE_FAST) return fail(RT_ERR_INVALID, "unknown mode");
+    if (seed < 0) return fail(RT_ERR_INVALID, "bad Seed must be non-negative");
+    const Replica& rep = *scene->replicas[0];
+    for (uint64_t i = 0; i < n; i++) {
+        if (hits[i].material < 0 || (size_t)hits[i].material >= scene->n_materials) return fail(RT_ERR_INVALID, "material index out of range");
+        if (hits[i].node < 0 || (size_t)hits[i].node >= scene->nodes.size()) return fail(RT_ERR_INVALID, "node index out of range");
+    }
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(rep.device));
+    DeviceBuffers tmp;
+    rt_shade_in* hd = nullptr;
+    rt_shade_out* od = nullptr;
+    HIP_TRY(tmp.alloc(n, &hd));
+    HIP_TRY(tmp.alloc(n, &od));
+    HIP_TRY(hipMemcpy(hd, hits, n * sizeof(rt_shade_in), hipMemcpyHostToDevice));
+    launch_shade_batch(rep.dev, hd, n, (uint32_t)((uint64_t)seed & 0xffffffffu), (uint32_t)((uint64_t)seed >> 32), mode, od, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, od, n * sizeof(rt_shade_out), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -860,11 +860,34 @@ class DeviceScene:
                                                 C.cast(hits.ctypes.data, C.POINTER(abi.Hit))), self._lib)
         return hits
 
+    def shade(self, hits: np.ndarray, seed=0, mode=abi.MODE_REFERENCE) -> np.ndarray:
+        """Material.Resolve + ComputeDirectLighting for explicit hits (rt_shade_batch): hits is an array of
+        abi.SHADE_IN_DTYPE, the result one of abi.SHADE_OUT_DTYPE."""
+        from . import _lib
+        h = np.ascontiguousarray(hits, dtype=abi.SHADE_IN_DTYPE)
+        out = np.zeros(len(h), dtype=abi.SHADE_OUT_DTYPE)
+        _lib.check(self._lib.rt_shade_batch(self.handle, h.ctypes.data, len(h), int(seed), int(mode), out.ctypes.data), self._lib)
+        return out
+
     def bvh_info(self, mesh_index=0) -> abi.BvhInfo:
         from . import _lib
         info = abi.BvhInfo()
         _lib.check(self._lib.rt_scene_bvh_info(self.handle, mesh_index, C.byref(info)), self._lib)
         return info
+
+
+def microfacet_batch(which: int, roughness, f0, args) -> np.ndarray:
+    """MicrofacetBRDF.D / G1 / G / F / Evaluate on the device (rt_microfacet_batch).  args: (n, 4, 3) in the order of the
+    Go signature (unused vectors zero); returns (n, 3), scalar results in column 0."""
+    from . import _lib
+    lib = _lib.load()
+    a = np.ascontiguousarray(args, dtype=np.float64).reshape(-1, 4, 3)
+    r = np.ascontiguousarray(np.broadcast_to(np.asarray(roughness, dtype=np.float64), (len(a),)))
+    f = np.ascontiguousarray(np.broadcast_to(np.asarray(f0, dtype=np.float64), (len(a), 3)))
+    out = np.zeros((len(a), 3))
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    _lib.check(lib.rt_microfacet_batch(int(which), len(a), dp(r), dp(f), dp(a), dp(out)), lib)
+    return out
 
 
 def stats_from(st: abi.Stats, options: RenderOptions) -> RenderStats:

@@ -50,7 +50,7 @@ def test_struct_sizes_match_the_header():
              ("rt_texture", abi.Texture), ("rt_material", abi.Material), ("rt_light", abi.Light), ("rt_node", abi.Node),
              ("rt_scene_desc", abi.SceneDesc), ("rt_camera_desc", abi.CameraDesc), ("rt_render_opts", abi.RenderOpts),
              ("rt_stats", abi.Stats), ("rt_hit", abi.Hit), ("rt_bvh_info", abi.BvhInfo), ("rt_obj_event", abi.ObjEvent),
-             ("rt_obj_scan", abi.ObjScan)]
+             ("rt_obj_scan", abi.ObjScan), ("rt_shade_in", abi.ShadeIn), ("rt_shade_out", abi.ShadeOut)]
     src = '#include <stdio.h>\n#include "rt_hip.h"\nint main(void){' + "".join(
         f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n"
     with tempfile.TemporaryDirectory() as d:
