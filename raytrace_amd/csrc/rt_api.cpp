@@ -450,6 +450,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         if (nodes[i].pad) walk_nodes.push_back((int32_t)i);
     }
     sc->nodes = nodes;
+    // RT_STACK_PAIRS: a test knob that gives the traversal stacks fewer entries than the deepest tree needs, to
+    // exercise the overflow report (a render then fails with RT_ERR_DEVICE instead of returning a wrong image)
+    if (const char* e = std::getenv("RT_STACK_PAIRS")) stack_pairs = std::max(1, std::atoi(e));
     DScene proto{};
     proto.n_walk_nodes = (int32_t)walk_nodes.size();
     proto.n_nodes = (int32_t)d->n_nodes;

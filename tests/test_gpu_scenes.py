@@ -374,3 +374,57 @@ def test_small_queues_park_rays_and_give_the_same_image(name, monkeypatch):
     assert small.Stats.TraverseLaunches > 2 * big.Stats.TraverseLaunches
     diff = np.abs(big.Image.astype(int) - small.Image.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+
+
+def test_three_cameras_on_one_scene_handle_match_the_oracle(ob):
+    # The animation loop keeps the scene resident and changes only the camera (example/charuco/main.go:259-339).  The
+    # cost-ordered tile schedule and the occupancy map are cached per camera: 3072 tiles x 32 samples keeps both live,
+    # and every frame must still be the oracle's, also when an earlier camera comes back.
+    sc = scenes.scan(level=5, dx=512, dy=384, spp=32, tex_size=128)
+    sc.Node.append(phys.Node("ball", phys.Sphere((0.0, 150.0, 40.0), 30.0), phys.DebugNormal()))
+    o = sc.RenderOptions
+    # (not the example's camera 100 m away: from there the float64 discriminant of Sphere.Collide, ~1e22, has lost a
+    # sphere of radius 30 altogether, and the reference's image of it is rounding noise)
+    ortho = phys.OrthographicCamera(LookFrom=(600.0, 0.0, 600.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0), FOVHeight=300.0, FOVWidth=400.0)
+    pin = phys.PinholeCamera(LowerLeftCorner=(-60.0, -600.0, -45.0), Origin=(0.0, -900.0, 0.0), Horizontal=(120.0, 0.0, 0.0),
+                             Vertical=(0.0, 0.0, 90.0))
+    cal = phys.CalibratedCamera(Intrinsics=phys.IntrinsicsFireflyDLGeneric6mm,
+                                Extrinsics=phys.CameraExtrinsics(LookFrom=(500.0, -400.0, 300.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0)))
+    ortho2 = phys.OrthographicCamera(LookFrom=(0.0, 800.0, 160.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0), FOVHeight=300.0, FOVWidth=400.0)
+    with phys.DeviceScene(sc) as dev, ob.OracleScene(sc) as orc:
+        want = {}
+        for name, cam in (("ortho", ortho), ("pinhole", pin), ("calibrated", cal), ("ortho2", ortho2)):
+            want[name] = orc.render(cam, o)
+        for name, cam in (("ortho", ortho), ("pinhole", pin), ("calibrated", cal), ("ortho2", ortho2), ("ortho", ortho), ("pinhole", pin)):
+            art = dev.render(cam, o, abi.MODE_FAST)
+            img, st, _, _ = want[name]
+            assert art.Stats.TotalRays == st.total_rays and art.Stats.RaysLeftScene == st.rays_left_scene, name
+            diff = np.abs(art.Image.astype(int) - img.astype(int))
+            assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (name, diff.max(), (diff > 0).mean())
+            assert (img[..., :3].max(axis=2) > 0).mean() > 0.05, name  # the camera does see the scene
+
+
+def test_a_traversal_stack_that_runs_full_fails_the_render(monkeypatch):
+    # The host sizes every traversal stack from the deepest tree, so a full stack cannot happen; RT_STACK_PAIRS makes
+    # it happen.  A chain of faces along a line gives a deep tree; with room for 2 entries the walks must report the
+    # overflow and the render must fail instead of returning an image with holes.
+    n = 4096
+    faces = np.zeros((n, 3, 5))
+    x = np.arange(n) * 1.0
+    faces[:, 0, :3] = np.stack([x, np.zeros(n), np.zeros(n)], 1)
+    faces[:, 1, :3] = np.stack([x + 0.9, np.zeros(n), np.ones(n)], 1)
+    faces[:, 2, :3] = np.stack([x, np.ones(n), np.zeros(n)], 1)
+    cam = phys.OrthographicCamera(LookFrom=(n / 2, 0.3, 1000.0), LookAt=(n / 2, 0.3, 0.0), VUp=(0.0, 1.0, 0.0), FOVHeight=2.0, FOVWidth=float(n))
+    for mat, lights in ((phys.Emitter(phys.TextureUniform((1.0, 1.0, 1.0))), []),
+                        (phys.Lambertian(phys.TextureUniform((0.5, 0.5, 0.5))), [phys.PointLight((n / 2, 5.0, 50.0), (1.0, 1.0, 1.0))])):
+        sc = phys.Scene(Camera=[cam], Node=[phys.Node("chain", phys.NewMesh(faces), mat)], Light=lights,
+                        RenderOptions=phys.RenderOptions(0, 4, 3, 2048, 16))
+        monkeypatch.delenv("RT_STACK_PAIRS", raising=False)
+        with phys.DeviceScene(sc) as dev:
+            ok = dev.render(cam, sc.RenderOptions, abi.MODE_FAST)
+            assert ok.Image[..., :3].any()
+        monkeypatch.setenv("RT_STACK_PAIRS", "2")
+        with phys.DeviceScene(sc) as dev:
+            with pytest.raises(RuntimeError, match="traversal stack"):
+                dev.render(cam, sc.RenderOptions, abi.MODE_FAST)
+        monkeypatch.delenv("RT_STACK_PAIRS")
