@@ -316,6 +316,28 @@ const char* rt_last_error(void);
 int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* rt_scene_create from the text Scene.MarshalJSON writes (scene.go:82-114; the
+ * {"Type","Data"} wrapping of every interface value is json.go:52-100), for a
+ * host that holds a scene as JSON -- an exported file, the body of the
+ * playground's POST /raytrace/render (playground/main.go:66-110) -- and would
+ * otherwise decode it only to flatten it again.  Reads everything the
+ * reference writes: the registered types, PinholeCamera / FocusableCamera /
+ * Triangle (written but never registered there), untagged interface fields
+ * (Lambertian.Texture, TransformedShape.Shape) and image pixels carried
+ * inline (image.NRGBA / image.RGBA64 as encoding/json writes them).  A mesh's
+ * BVH member is skipped: the library builds that tree from the faces.  A
+ * TextureImage without pixels is RT_ERR_UNSUPPORTED (the library decodes no
+ * image files).  info (may be NULL) receives the RenderOptions as render
+ * options (mode RT_MODE_FAST, one band) and the first cameras of the text. */
+typedef struct rt_json_scene_info {
+    rt_render_opts opts;
+    uint64_t n_cameras; /* len(Scene.Camera); cameras[] holds the first 4 */
+    uint64_t n_nodes;
+    uint64_t n_lights;
+    rt_camera_desc cameras[4];
+} rt_json_scene_info;
+int rt_scene_create_from_json(const char* text, size_t len, rt_scene** out, rt_json_scene_info* info);
+
 /* Replacement for the body of renderScene (render.go:285-349): renders
  * opts->dx x opts->dy pixels with opts->rays_per_pixel samples each and writes
  * 8-bit RGBA (A = 255, row 0 = top) into rgba_out, `stride` bytes per row, the

@@ -11,7 +11,7 @@ _PATH = os.environ.get("RT_LIB_PATH") or os.path.join(os.path.dirname(os.path.ab
 SYMBOLS = [
     "rt_apply_filter", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
     "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info", "rt_obj_scan_text", "rt_obj_scan_free",
-    "rt_bvh_build", "rt_render_film_noalloc", "rt_microfacet_batch", "rt_shade_batch",
+    "rt_bvh_build", "rt_render_film_noalloc", "rt_microfacet_batch", "rt_shade_batch", "rt_scene_create_from_json",
 ]
 
 
@@ -42,6 +42,8 @@ def open_library() -> C.CDLL:
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_scene_create.argtypes = [P(abi.SceneDesc), P(C.c_void_p)]
     lib.rt_scene_create.restype = C.c_int
+    lib.rt_scene_create_from_json.argtypes = [C.c_char_p, C.c_size_t, P(C.c_void_p), P(abi.JsonSceneInfo)]
+    lib.rt_scene_create_from_json.restype = C.c_int
     lib.rt_scene_destroy.argtypes = [C.c_void_p]
     lib.rt_scene_destroy.restype = None
     lib.rt_render.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), P(C.c_uint8), C.c_size_t, P(abi.Stats)]

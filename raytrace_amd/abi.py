@@ -140,6 +140,11 @@ class Stats(C.Structure):
     ]
 
 
+class JsonSceneInfo(C.Structure):  # rt_json_scene_info
+    _fields_ = [("opts", RenderOpts), ("n_cameras", C.c_uint64), ("n_nodes", C.c_uint64), ("n_lights", C.c_uint64),
+                ("cameras", CameraDesc * 4)]
+
+
 class Hit(C.Structure):
     _fields_ = [
         ("node", C.c_int32), ("prim", C.c_int32), ("t", C.c_double), ("at", D3), ("normal", D3),

@@ -774,6 +774,8 @@ class FlatScene:
 
 
 def camera_desc(cam) -> abi.CameraDesc:
+    if isinstance(cam, abi.CameraDesc):
+        return cam
     if isinstance(cam, AnimatedCamera):
         cam = cam.Resolve()
     d = abi.CameraDesc()
@@ -822,6 +824,23 @@ class DeviceScene:
         self.flat = FlatScene(scene)
         self.handle = C.c_void_p()
         _lib.check(self._lib.rt_scene_create(C.byref(self.flat.desc), C.byref(self.handle)), self._lib)
+
+    @classmethod
+    def from_json(cls, text):
+        """rt_scene_create_from_json: the text of Scene.MarshalJSON (scene.go:82-114) read by the library itself.
+        Returns (DeviceScene, cameras, RenderOptions): the cameras as abi.CameraDesc, which render() accepts."""
+        from . import _lib
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self.flat = None
+        self.handle = C.c_void_p()
+        raw = text.encode() if isinstance(text, str) else bytes(text)
+        info = abi.JsonSceneInfo()
+        _lib.check(self._lib.rt_scene_create_from_json(raw, len(raw), C.byref(self.handle), C.byref(info)), self._lib)
+        o = info.opts
+        self.json_info = info
+        cameras = [info.cameras[i] for i in range(min(int(info.n_cameras), len(info.cameras)))]
+        return self, cameras, RenderOptions(o.seed, o.rays_per_pixel, o.max_ray_depth, o.dx, o.dy)
 
     def close(self):
         if self.handle:

@@ -50,7 +50,8 @@ def test_struct_sizes_match_the_header():
              ("rt_texture", abi.Texture), ("rt_material", abi.Material), ("rt_light", abi.Light), ("rt_node", abi.Node),
              ("rt_scene_desc", abi.SceneDesc), ("rt_camera_desc", abi.CameraDesc), ("rt_render_opts", abi.RenderOpts),
              ("rt_stats", abi.Stats), ("rt_hit", abi.Hit), ("rt_bvh_info", abi.BvhInfo), ("rt_obj_event", abi.ObjEvent),
-             ("rt_obj_scan", abi.ObjScan), ("rt_shade_in", abi.ShadeIn), ("rt_shade_out", abi.ShadeOut)]
+             ("rt_obj_scan", abi.ObjScan), ("rt_shade_in", abi.ShadeIn), ("rt_shade_out", abi.ShadeOut),
+             ("rt_json_scene_info", abi.JsonSceneInfo)]
     src = '#include <stdio.h>\n#include "rt_hip.h"\nint main(void){' + "".join(
         f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n"
     with tempfile.TemporaryDirectory() as d:
@@ -93,3 +94,38 @@ def test_bvh_node_record_matches_the_header():
     dt = np.dtype(abi.BVH_NODE_DTYPE)
     got = [dt.itemsize] + [dt.fields[k][1] for k in ("bounds_min", "bounds_max", "right", "first", "count")]
     assert got == want
+
+
+def test_json_reader_parses_on_the_host_and_stops_at_the_missing_gpu():
+    """rt_scene_create_from_json reads the whole text before it touches a device: a malformed or unsupported text is
+    reported as such on any machine, and a text that reads well ends at rt_scene_create (no GPU here: not initialised)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from raytrace_amd import abi, scenes
+    lib = library()
+
+    def rc(text):
+        raw = text.encode()
+        h = C.c_void_p()
+        code = lib.rt_scene_create_from_json(raw, len(raw), C.byref(h), None)
+        assert not h.value
+        return code, (lib.rt_last_error() or b"").decode()
+
+    for sc in (scenes.cornell(dx=16, dy=16, spp=1), scenes.material(dx=16, dy=16, spp=1, tex_size=(8, 8)),
+               scenes.scan(level=2, dx=16, dy=16, spp=1, tex_size=8, lit=True)):
+        code, msg = rc(sc.MarshalJSON())
+        assert code == abi.RT_ERR_NOT_INITIALIZED, msg
+    for text, want in [
+        ('{"Node":[{"Name":"a"', "unexpected end of JSON input"),
+        ('{"Camera":[{"Data":{},"Type":"FisheyeCamera"}]}', "unsupported type: `FisheyeCamera`; has it been registered?"),
+        ('{"Light":[{"Data":{},"Type":"Sphere"}]}', "expected Light, got *phys.Sphere"),
+        ('{"Node":[{"Name":"n","Material":{"Data":{},"Type":"DebugUV"},"Shape":{"Data":{"Center":{"X":"1"}},"Type":"Sphere"}}]}',
+         "not a number"),
+        ('{"Node":[{"Name":"n","Material":{"Data":{},"Type":"DebugUV"},"Shape":{"Data":{"Face":[],"BVH":{"Type":"Group"}},"Type":"Mesh"}}]}',
+         "invalid type: expected BVH, got Group"),
+        ('{"RenderOptions":{"Dx":1.5}}', "fraction"),
+        ('{"Node":[]} x', "after top-level value"),
+    ]:
+        code, msg = rc(text)
+        assert code == abi.RT_ERR_INVALID and want in msg, (text, code, msg)
