@@ -345,6 +345,22 @@ int rt_scene_create_from_json(const char* text, size_t len, rt_scene** out, rt_j
 int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts,
               uint8_t* rgba_out, size_t stride, rt_stats* stats);
 
+/* A frame loop over one resident scene: frame i is rt_render with cameras[i],
+ * written to rgba_out + i * frame_stride (rows `stride` bytes apart).  This is
+ * the loop of example/charuco (main.go:259-339: one scene, a camera per frame,
+ * every frame a full phys.Render) and of the lab's orbit viewer
+ * (lab/worker/worker.go:214-267) moved behind the boundary, so that with
+ * overlap != 0 the quantised image of frame i crosses PCIe and is copied into
+ * the caller's memory (second host thread, second set of film / staging
+ * buffers) while frame i + 1 is being traced.  overlap == 0 runs the frames
+ * strictly one after the other, as n calls of rt_render would.  The frames are
+ * the same bytes either way.  stats (may be NULL) has n_frames entries;
+ * render_seconds of an entry is the time to trace and enqueue that frame.
+ * On an error (RT_ERR_CANCELLED included) the frames already handed over stay
+ * valid and the rest are unspecified. */
+int rt_render_frames(rt_scene* scene, const rt_camera_desc* cameras, int32_t n_frames, const rt_render_opts* opts,
+                     uint8_t* rgba_out, size_t stride, size_t frame_stride, rt_stats* stats, int32_t overlap);
+
 /* The same render, stopping before quantisation: adds this call's radiance sums
  * into film_dev, a DEVICE buffer of dx*dy*3 float64 (row 0 = top, RGB), which
  * the caller zeroes first.  With band sharding each process fills only its

@@ -11,7 +11,7 @@ _PATH = os.environ.get("RT_LIB_PATH") or os.path.join(os.path.dirname(os.path.ab
 SYMBOLS = [
     "rt_apply_filter", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_film",
     "rt_film_resolve", "rt_cancel", "rt_intersect_batch", "rt_cast_batch", "rt_scene_bvh_info", "rt_obj_scan_text", "rt_obj_scan_free",
-    "rt_bvh_build", "rt_render_film_noalloc", "rt_microfacet_batch", "rt_shade_batch", "rt_scene_create_from_json",
+    "rt_bvh_build", "rt_render_film_noalloc", "rt_microfacet_batch", "rt_shade_batch", "rt_scene_create_from_json", "rt_render_frames",
 ]
 
 
@@ -48,6 +48,9 @@ def open_library() -> C.CDLL:
     lib.rt_scene_destroy.restype = None
     lib.rt_render.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), P(C.c_uint8), C.c_size_t, P(abi.Stats)]
     lib.rt_render.restype = C.c_int
+    lib.rt_render_frames.argtypes = [C.c_void_p, P(abi.CameraDesc), C.c_int32, P(abi.RenderOpts), P(C.c_uint8), C.c_size_t, C.c_size_t,
+                                     P(abi.Stats), C.c_int32]
+    lib.rt_render_frames.restype = C.c_int
     lib.rt_render_film.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), C.c_void_p, P(abi.Stats)]
     lib.rt_render_film.restype = C.c_int
     lib.rt_render_film_noalloc.argtypes = [C.c_void_p, P(abi.CameraDesc), P(abi.RenderOpts), C.c_void_p, P(abi.Stats)]

@@ -101,7 +101,8 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
 // The whole frame over every replica of the scene: bands of rows or runs of samples per device, combined on the first device.
 int render_all_devices(rt_scene* sc, const rt_camera_desc* camera, const rt_render_opts* o, double* film, rt_stats* stats);
 // Scratch buffers owned by a replica for rt_render (film sums, the 8-bit image and its pinned host copy), grown on demand.
-int scene_film(const rt_scene* sc, Replica& rep, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host);
+// There are two such sets (slot 0 / 1): a frame loop alternates between them.
+int scene_film(const rt_scene* sc, Replica& rep, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host, int slot = 0);
 // The WorkBuffers that live in the static scratch of `device` (see kernels.hip); null with a message when the frame does not fit.
 WorkBuffers* static_work_for(int device, int64_t tiles_total);
 }  // namespace rt

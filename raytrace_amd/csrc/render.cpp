@@ -35,11 +35,15 @@ struct WorkBuffers {
     RayQ pool{};     // overflow stack for generations that outgrow q (Dielectric's two children)
     uint64_t pool_capacity = 0;
     void* pool_base = nullptr;
-    uint8_t* rgba = nullptr;
-    uint8_t* rgba_host = nullptr;  // pinned staging copy of rgba: the caller's buffer is pageable
-    size_t rgba_bytes = 0;
-    double* film = nullptr;
-    size_t film_doubles = 0;
+    // Film sums, the 8-bit image and its pinned staging copy (the caller's buffer is pageable) for rt_render; a frame
+    // loop (rt_render_frames) alternates between two such sets so that one frame copies out while the next is traced.
+    struct Frame {
+        uint8_t* rgba = nullptr;
+        uint8_t* rgba_host = nullptr;
+        size_t rgba_bytes = 0;
+        double* film = nullptr;
+        size_t film_doubles = 0;
+    } frame[2];
     // Cost-ordered schedule of the primary launch, measured by a short pilot pass and kept while the
     // camera and the frame stay the same (animation frames and progressive passes re-use it).
     uint32_t* tile_cost = nullptr;
@@ -55,9 +59,11 @@ struct WorkBuffers {
 void destroy_work(WorkBuffers* w) {
     if (!w || w->is_static) return;
     if (w->pool_base) (void)hipFree(w->pool_base);
-    if (w->rgba) (void)hipFree(w->rgba);
-    if (w->rgba_host) (void)hipHostFree(w->rgba_host);
-    if (w->film) (void)hipFree(w->film);
+    for (WorkBuffers::Frame& f : w->frame) {
+        if (f.rgba) (void)hipFree(f.rgba);
+        if (f.rgba_host) (void)hipHostFree(f.rgba_host);
+        if (f.film) (void)hipFree(f.film);
+    }
     if (w->tile_cost) (void)hipFree(w->tile_cost);
     if (w->tile_order) (void)hipFree(w->tile_order);
     delete w;
@@ -407,9 +413,9 @@ WorkBuffers* static_work_for(int device, int64_t tiles_total) {
     return &w;
 }
 
-int scene_film(const rt_scene* sc, Replica& rep, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host) {
+int scene_film(const rt_scene* sc, Replica& rep, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host, int slot) {
     if (int rc = ensure_work(sc, rep)) return rc;
-    WorkBuffers& w = *rep.work;
+    WorkBuffers::Frame& w = rep.work->frame[slot & 1];
     const size_t px = (size_t)dx * dy;
     if (w.rgba_bytes < px * 4) {
         if (w.rgba) (void)hipFree(w.rgba);

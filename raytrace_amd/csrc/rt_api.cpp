@@ -5,13 +5,16 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -640,6 +643,117 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opt
         fprintf(stderr, "[rt] rt_render: film %.3f ms, resolve + copy out %.3f ms\n", std::chrono::duration<double>(t1 - t0).count() * 1e3,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() * 1e3);
     if (stats) stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_render_frames(rt_scene* scene, const rt_camera_desc* cameras, int32_t n_frames, const rt_render_opts* opts, uint8_t* rgba_out,
+                     size_t stride, size_t frame_stride, rt_stats* stats, int32_t overlap) {
+    if (!scene || !opts || !rgba_out || (n_frames > 0 && !cameras)) return fail(RT_ERR_INVALID, "null argument");
+    if (n_frames < 0) return fail(RT_ERR_INVALID, "n_frames must not be negative");
+    if (opts->dx <= 0 || opts->dy <= 0) return fail(RT_ERR_INVALID, "bad Dx / Dy must be positive");
+    const size_t row = (size_t)opts->dx * 4;
+    if (stride < row) return fail(RT_ERR_INVALID, "stride smaller than a row");
+    if (n_frames > 1 && frame_stride < stride * (size_t)(opts->dy - 1) + row) return fail(RT_ERR_INVALID, "frame_stride smaller than a frame");
+    if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    if (n_frames == 0) return RT_OK;
+    Replica& first = *scene->replicas[0];
+    HIP_TRY(hipSetDevice(first.device));
+    const int depth = overlap && n_frames > 1 ? 2 : 1;
+    double* film[2] = {};
+    uint8_t *rgba[2] = {}, *host[2] = {};
+    for (int s = 0; s < depth; s++)
+        if (int rc = scene_film(scene, first, opts->dx, opts->dy, &film[s], &rgba[s], &host[s], s)) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(opts->stream);
+
+    // Copies go out on a stream of their own (not synchronised with the null stream) and are moved from the pinned
+    // staging buffer into the caller's frames by a second host thread, so that neither holds up the next frame's trace.
+    struct Pipe {
+        hipStream_t copy = nullptr;
+        hipEvent_t resolved[2] = {}, copied[2] = {};
+        ~Pipe() {
+            for (hipEvent_t e : resolved) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : copied) if (e) (void)hipEventDestroy(e);
+            if (copy) (void)hipStreamDestroy(copy);
+        }
+    } pipe;
+    HIP_TRY(hipStreamCreateWithFlags(&pipe.copy, hipStreamNonBlocking));
+    for (int s = 0; s < depth; s++) {
+        HIP_TRY(hipEventCreateWithFlags(&pipe.resolved[s], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&pipe.copied[s], hipEventDisableTiming));
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    int submitted = 0, drained = 0;
+    bool closed = false;
+    hipError_t drain_error = hipSuccess;
+    std::thread drain([&]() {
+        (void)hipSetDevice(first.device);
+        for (int i = 0;; i++) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return submitted > i || closed; });
+                if (submitted <= i) return;
+            }
+            const int s = i % depth;
+            hipError_t e = hipEventSynchronize(pipe.copied[s]);
+            if (e == hipSuccess) {
+                uint8_t* dst = rgba_out + (size_t)i * frame_stride;
+                if (stride == row) std::memcpy(dst, host[s], row * (size_t)opts->dy);
+                else
+                    for (int y = 0; y < opts->dy; y++) std::memcpy(dst + (size_t)y * stride, host[s] + (size_t)y * row, row);
+            }
+            std::lock_guard<std::mutex> lock(mu);
+            if (e != hipSuccess && drain_error == hipSuccess) drain_error = e;
+            drained = i + 1;
+            cv.notify_all();
+        }
+    });
+    auto finish = [&]() {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            closed = true;
+        }
+        cv.notify_all();
+        drain.join();
+    };
+
+    int rc = RT_OK;
+    std::string message;
+    hipError_t e = hipSuccess;
+    const size_t n = (size_t)opts->dx * opts->dy * 3;
+    for (int i = 0; i < n_frames && rc == RT_OK && e == hipSuccess; i++) {
+        const int s = i % depth;
+        {  // the set's staging buffer is free once the frame that used it last has been handed over
+            std::unique_lock<std::mutex> lock(mu);
+            cv.wait(lock, [&] { return drained > i - depth; });
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        rt_stats st{};
+        e = hipMemsetAsync(film[s], 0, n * sizeof(double), stream);
+        if (e != hipSuccess) break;
+        rc = render_all_devices(scene, &cameras[i], opts, film[s], &st);
+        if (rc != RT_OK) {
+            message = last_error_text();
+            break;
+        }
+        launch_resolve(film[s], opts->dx, opts->dy, opts->rays_per_pixel, rgba[s], stream);
+        e = hipEventRecord(pipe.resolved[s], stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pipe.copy, pipe.resolved[s], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(host[s], rgba[s], row * (size_t)opts->dy, hipMemcpyDeviceToHost, pipe.copy);
+        if (e == hipSuccess) e = hipEventRecord(pipe.copied[s], pipe.copy);
+        if (e != hipSuccess) break;
+        st.render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (stats) stats[i] = st;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            submitted = i + 1;
+        }
+        cv.notify_all();
+    }
+    finish();
+    if (rc != RT_OK) return fail(rc, message);
+    if (e == hipSuccess) e = drain_error;
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("rt_render_frames: ") + hipGetErrorString(e));
     return RT_OK;
 }
 

@@ -377,32 +377,37 @@ def decode_png(data: bytes) -> np.ndarray:
     bpp = max(1, channels * depth // 8)  # bytes per complete pixel, for the filters
     stride = (w * channels * depth + 7) // 8
     rows = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
+    prev = bytes(stride)
+    lanes = -(-stride // bpp) * bpp
     for y in range(h):
         ft = raw[y * (stride + 1)]
-        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=y * (stride + 1) + 1).astype(np.int32)
+        line = raw[y * (stride + 1) + 1:(y + 1) * (stride + 1)]
         if ft == 0:
             cur = line
         elif ft == 2:
-            cur = (line + prev) & 255
-        else:  # Sub, Average and Paeth depend on the pixel to the left: byte-serial per row
-            cur = line.copy()
-            for i in range(stride):
-                a = cur[i - bpp] if i >= bpp else 0
+            cur = ((np.frombuffer(line, dtype=np.uint8).astype(np.int32) + np.frombuffer(prev, dtype=np.uint8)) & 255).astype(np.uint8).tobytes()
+        elif ft == 1:  # Sub: a running sum per byte lane of the pixel
+            lane = np.zeros(lanes, dtype=np.int64)
+            lane[:stride] = np.frombuffer(line, dtype=np.uint8)
+            cur = (np.cumsum(lane.reshape(-1, bpp), axis=0) & 255).astype(np.uint8).reshape(-1)[:stride].tobytes()
+        elif ft in (3, 4):  # Average and Paeth depend on the byte to the left and the row above: byte-serial
+            cur = bytearray(line)
+            for i in range(min(bpp, stride)):
                 b = prev[i]
-                c = prev[i - bpp] if i >= bpp else 0
-                if ft == 1:
-                    pred = a
-                elif ft == 3:
-                    pred = (a + b) >> 1
-                elif ft == 4:
+                cur[i] = (cur[i] + ((b >> 1) if ft == 3 else b)) & 255
+            if ft == 3:
+                for i in range(bpp, stride):
+                    cur[i] = (cur[i] + ((cur[i - bpp] + prev[i]) >> 1)) & 255
+            else:
+                for i in range(bpp, stride):
+                    a, b, c = cur[i - bpp], prev[i], prev[i - bpp]
                     p = a + b - c
                     pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
-                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                else:
-                    raise ValueError("png: bad filter type")
-                cur[i] = (cur[i] + pred) & 255
-        rows[y] = cur
+                    cur[i] = (cur[i] + (a if (pa <= pb and pa <= pc) else (b if pb <= pc else c))) & 255
+            cur = bytes(cur)
+        else:
+            raise ValueError("png: bad filter type")
+        rows[y] = np.frombuffer(cur, dtype=np.uint8)
         prev = cur
     if depth == 16:
         px = rows.reshape(h, -1, 2).astype(np.uint32)

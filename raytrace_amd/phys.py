@@ -869,6 +869,20 @@ class DeviceScene:
                                        options.Dx * 4, C.byref(st)), self._lib)
         return RenderArtifact(img, stats_from(st, options))
 
+    def render_frames(self, cameras, options: RenderOptions, mode=abi.MODE_FAST, overlap=True, out=None):
+        """rt_render_frames: one frame per camera over this resident scene (the loop of example/charuco/main.go:259-339).
+        Returns ((n, Dy, Dx, 4) uint8, [RenderStats]); with overlap a frame copies out while the next one is traced."""
+        from . import _lib
+        n = len(cameras)
+        descs = (abi.CameraDesc * max(1, n))(*[camera_desc(c) for c in cameras])
+        imgs = np.zeros((n, options.Dy, options.Dx, 4), dtype=np.uint8) if out is None else out
+        assert imgs.shape == (n, options.Dy, options.Dx, 4) and imgs.dtype == np.uint8 and imgs.flags.c_contiguous
+        st = (abi.Stats * max(1, n))()
+        ro = render_opts(options, mode)
+        _lib.check(self._lib.rt_render_frames(self.handle, descs, n, C.byref(ro), imgs.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                              options.Dx * 4, options.Dx * 4 * options.Dy, st, 1 if overlap else 0), self._lib)
+        return imgs, [stats_from(st[i], options) for i in range(n)]
+
     def intersect(self, origins, directions, tmin=EPS, tmax=1.7976931348623157e308, mode=abi.MODE_REFERENCE):
         from . import _lib
         o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)

@@ -11,6 +11,7 @@ where they exist: copies live in raytrace_amd/assets.
 """
 from __future__ import annotations
 
+import functools
 import gzip
 import json
 import math
@@ -32,9 +33,13 @@ def asset_bytes(name: str) -> bytes:
     return gzip.decompress(data) if name.endswith(".gz") else data
 
 
+@functools.lru_cache(maxsize=None)
 def asset_image(name: str) -> np.ndarray:
+    """A decoded image asset, shared by every scene that uses it (read-only)."""
     from . import obj
-    return obj.decode_png(asset_bytes(name))
+    img = obj.decode_png(asset_bytes(name))
+    img.setflags(write=False)
+    return img
 
 
 def teapot_faces() -> np.ndarray:
