@@ -715,4 +715,287 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
     return hit;
 }
 
+// ---- pixel beams -------------------------------------------------------------------------------
+//
+// The 64 lanes of a primary wave trace samples of ONE pixel.  Under an orthographic camera those rays are parallel and
+// start inside the pixel's footprint on the image plane, a parallelogram a fraction of a face wide: instead of walking
+// the tree once per round of 64 samples (mesh_collide_packet), the tree is walked ONCE per pixel for the whole bundle --
+// a "fat ray": the centre ray against boxes grown by the half-extent of the footprint -- by a single lane, while
+// neighbouring lanes do the same for the neighbouring pixels of the work item.  The walk prunes nothing by distance (it
+// does not know where the samples will hit); it lists the leaves the bundle can reach, nearest first, with the bundle's
+// entry distance.  Every sample then tests only the faces of those leaves (beam_test), with the same float32 pre-test
+// and float64 intersection as the other walks, so the hit it finds is the one they find.
+//
+// Why the list cannot miss a face: a sample's ray enters a (padded) box no earlier and leaves it no later, axis by
+// axis, than the fat ray enters / leaves the box grown by the footprint, so whenever the per-ray slab test of
+// mesh_collide_fast passes, the fat ray's passes; float32 rounding of the bundle's own numbers is covered by a margin of
+// 2^-21 of the mesh radius on top of the boxes' padding.
+
+constexpr int kBeamPixels = 8;      // pixels of a work item at most (one lane walks each)
+constexpr int kBeamCands = 48;      // faces listed per pixel at a time; a longer list is produced in instalments
+constexpr int kBeamStateDwords = 32;
+
+// What a lane's walk keeps between instalments, in LDS (dwords): 0-2 a, 3-5 b (slab distance of a min plane p is
+// p * i + a, of a max plane p * i + b), 6-8 i = 1 / direction, 9 t_lo (where the rays start, in the bundle's frame),
+// 10-11 T (float64: the frame starts at o + d * T), 12 cur, 13 sp, 14 entry distance of cur, 15 the caller's (length
+// of the list), 16-18 origin of the centre ray in that frame, 19-21 half-extent of the footprint (margins included),
+// 22-24 direction (float32).
+//
+// Sets the walk of the pixel (lx, y) up.  False: the bundle misses the mesh.
+RT_DEV bool beam_setup(const DCamera& cam, int32_t dx_img, int32_t dy_img, const DMesh& m, int lx, int y, int32_t* state) {
+    // camera_orthographic.go:24-46: o = from + u * (fov_w * (s - 0.5)) + v * (fov_h * (t - 0.5)), s in [lx, lx + 1] / dx, t in [y, y + 1] / dy
+    const double a0 = cam.fov_w * ((double)lx / (double)dx_img - 0.5), a1 = cam.fov_w * ((double)(lx + 1) / (double)dx_img - 0.5);
+    const double b0 = cam.fov_h * ((double)y / (double)dy_img - 0.5), b1 = cam.fov_h * ((double)(y + 1) / (double)dy_img - 0.5);
+    double c[3], e[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double ua = cam.u[k] * a0, ub = cam.u[k] * a1, va = cam.v[k] * b0, vb = cam.v[k] * b1;
+        const double lo = cam.from[k] + fmin(ua, ub) + fmin(va, vb), hi = cam.from[k] + fmax(ua, ub) + fmax(va, vb);
+        c[k] = 0.5 * (lo + hi);
+        // the samples' own arithmetic rounds differently from this one: a relative 1e-12 dwarfs every such difference
+        e[k] = 0.5 * (hi - lo) + 1e-12 * (fabs(cam.from[k]) + fabs(ua) + fabs(ub) + fabs(va) + fabs(vb));
+    }
+    // the centre ray against the root box grown by the footprint (as fast_setup clips a single ray)
+    double t_in = 0, t_out = kMaxFloat;
+    const double pad = (double)m.pad;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double inv = near_reciprocal(cam.dir[k]);
+        const double t0 = ((m.root_box[k] - pad - e[k]) - c[k]) * inv, t1 = ((m.root_box[3 + k] + pad + e[k]) - c[k]) * inv;
+        t_in = fmax(t_in, fmin(t0, t1));
+        t_out = fmin(t_out, fmax(t0, t1));
+    }
+    if (!(t_in <= t_out)) return false;
+    const double T = t_in;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double bc = (c[k] + cam.dir[k] * T) - m.center[k];
+        const float ocf = (float)bc;
+        const float ef = up32(e[k] + fabs(bc) * 1.1920929e-7 + (double)m.radius * 4.76837158203125e-7);  // + 2^-23 |o| + 2^-21 R
+        const float i = slab_inverse((float)cam.dir[k]);
+        state[k] = __float_as_int(-(ocf + ef) * i);
+        state[3 + k] = __float_as_int(-(ocf - ef) * i);
+        state[6 + k] = __float_as_int(i);
+        state[16 + k] = __float_as_int(ocf);
+        state[19 + k] = __float_as_int(ef);
+        state[22 + k] = __float_as_int((float)cam.dir[k]);
+    }
+    const float t_lo = -up32(T);
+    state[9] = __float_as_int(t_lo);
+    state[10] = (int32_t)(__double_as_longlong(T) & 0xffffffffll);
+    state[11] = (int32_t)(__double_as_longlong(T) >> 32);
+    state[12] = 0;
+    state[13] = 0;
+    state[14] = __float_as_int(t_lo);
+    return true;
+}
+
+// tri32_rejects for the whole bundle: true = the float64 test cannot accept this face for ANY ray of the bundle.  With
+// s = o - p0, U = s.(d x e2) and V = s.(e1 x d) are linear in the origin, so over the footprint (|o - centre| <= ext per
+// axis) they stay within dU = sum ext_k |(d x e2)_k| and dV = sum ext_k |(e1 x d)_k| of their values at the centre ray;
+// the face is dropped only when even the most favourable origin violates a bound by more than tri32_rejects' own margins.
+RT_DEV bool beam_rejects_face(const Tri32& t, float ox, float oy, float oz, float ex, float ey, float ez, float dx, float dy, float dz,
+                              float err_r, float err_d) {
+#pragma clang fp contract(fast)
+    const float hx = dy * t.e2[2] - dz * t.e2[1], hy = dz * t.e2[0] - dx * t.e2[2], hz = dx * t.e2[1] - dy * t.e2[0];
+    const float gx = t.e1[1] * dz - t.e1[2] * dy, gy = t.e1[2] * dx - t.e1[0] * dz, gz = t.e1[0] * dy - t.e1[1] * dx;  // e1 x d
+    const float a = t.e1[0] * hx + t.e1[1] * hy + t.e1[2] * hz;
+    const float sx = ox - t.p0[0], sy = oy - t.p0[1], sz = oz - t.p0[2];
+    const float U = sx * hx + sy * hy + sz * hz;
+    const float V = sx * gx + sy * gy + sz * gz;
+    const float slack = 1.0f + 1.0f / 65536.0f;  // the bounds themselves are rounded
+    const float dU = (ex * fabsf(hx) + ey * fabsf(hy) + ez * fabsf(hz)) * slack;
+    const float dV = (ex * fabsf(gx) + ey * fabsf(gy) + ez * fabsf(gz)) * slack;
+    const float eu = err_r * t.len2, ev = err_r * t.len1, ea = err_d * t.len1 * t.len2;
+    const float aa = fabsf(a);
+    if (!(aa > ea)) return false;  // sign of a uncertain: let the samples decide
+    const float us = a < 0 ? -U : U, vs = a < 0 ? -V : V;
+    return us + dU < -eu || vs + dV < -ev || (us - dU) + (vs - dV) > aa + eu + ev + ea;
+}
+
+// One instalment of a pixel's walk: up to kBeamCands leaves, (reference, entry distance, face mask) triples in cand.  The
+// walk is over when state[12] == kFastEmpty afterwards.  stack: this lane's own 2 * cap dwords.
+RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int cap, int32_t* cand, bool& overflow
+#ifdef RT_VISIT_STATS
+                     , uint32_t& steps
+#endif
+) {
+    const float ax = __int_as_float(state[0]), ay = __int_as_float(state[1]), az = __int_as_float(state[2]);
+    const float bx = __int_as_float(state[3]), by = __int_as_float(state[4]), bz = __int_as_float(state[5]);
+    const float ix = __int_as_float(state[6]), iy = __int_as_float(state[7]), iz = __int_as_float(state[8]);
+    const float t_lo = __int_as_float(state[9]);
+    int32_t cur = state[12];
+    int sp = state[13];
+    float cur_tn = __int_as_float(state[14]);
+    int count = 0;
+    auto pop = [&]() {
+        if (sp > 0) {
+            sp--;
+            cur = stack[2 * sp];
+            cur_tn = __int_as_float(stack[2 * sp + 1]);
+        } else {
+            cur = kFastEmpty;
+        }
+    };
+    while (cur != kFastEmpty) {
+        if (cur >= 0) {
+#ifdef RT_VISIT_STATS
+            steps++;
+#endif
+            const FastNode n = nodes[cur];
+            float tn[2];
+            bool go[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float x0 = __builtin_fmaf(n.b[k][0][0], ix, ax), x1 = __builtin_fmaf(n.b[k][0][1], ix, bx);
+                const float y0 = __builtin_fmaf(n.b[k][1][0], iy, ay), y1 = __builtin_fmaf(n.b[k][1][1], iy, by);
+                const float z0 = __builtin_fmaf(n.b[k][2][0], iz, az), z1 = __builtin_fmaf(n.b[k][2][1], iz, bz);
+                const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_lo));
+                const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                tn[k] = tnear;
+                go[k] = (tnear <= tfar) && n.child[k] != kFastEmpty;
+            }
+            if (go[0] && go[1]) {
+                const bool swap = tn[1] < tn[0];
+                if (sp < cap) {
+                    stack[2 * sp] = swap ? n.child[0] : n.child[1];
+                    stack[2 * sp + 1] = __float_as_int(swap ? tn[0] : tn[1]);
+                    sp++;
+                } else {
+                    overflow = true;  // the host sizes the stack from the deepest tree: cannot happen, but must not pass silently
+                }
+                cur = swap ? n.child[1] : n.child[0];
+                cur_tn = swap ? tn[1] : tn[0];
+            } else if (go[0] || go[1]) {
+                cur = go[0] ? n.child[0] : n.child[1];
+                cur_tn = go[0] ? tn[0] : tn[1];
+            } else {
+                pop();
+            }
+        } else {
+            if (count == kBeamCands) break;  // the list is full: the next instalment resumes at this leaf
+            cand[3 * count] = cur;
+            cand[3 * count + 1] = __float_as_int(cur_tn);
+            cand[3 * count + 2] = 0xff >> (7 - (int)((uint32_t)~cur & 7u));  // every face of the leaf, until beam_cull_item has looked
+            count++;
+            pop();
+        }
+    }
+    state[12] = cur;
+    state[13] = sp;
+    state[14] = __float_as_int(cur_tn);
+    return count;
+}
+
+// Turns the entry distances of a complete list into suffix minima: entry c then holds the smallest entry distance of
+// the leaves c, c + 1, ... that still have a face to offer.  The walk lists leaves nearest first only roughly; with the
+// minima a sample can stop at the first entry beyond its hit (nothing after it begins nearer) instead of looking at
+// every leaf of the far side of the mesh.
+RT_DEV void beam_suffix_min(int32_t* cand, int n) {
+    float m = __builtin_inff();
+    for (int c = n - 1; c >= 0; c--) {
+        if (cand[3 * c + 2] != 0) m = fminf(m, __int_as_float(cand[3 * c + 1]));
+        cand[3 * c + 1] = __float_as_int(m);
+    }
+}
+
+// The whole wave thins the complete lists of an item's pixels out: eight lanes per listed leaf, one per face, each
+// testing its face against the bundle of the leaf's pixel (beam_rejects_face); the faces that survive become the
+// leaf's mask.  All the faces of eight leaves are fetched at once, so an item pays a few memory round trips here
+// instead of one per face in every round.  prefix: 9 dwords of LDS.  Must be entered by all 64 lanes.
+RT_DEV void beam_cull_item(const Tri32* tri32, float radius, int32_t* beam_state, int32_t* beam_cand, int32_t* prefix, int n_px, int lane) {
+    int len = 0;
+    if (lane < n_px) {
+        const int32_t v = beam_state[lane * kBeamStateDwords + 15];
+        len = (v & 0x100) ? 0 : (v & 0xff);  // a list that goes on is walked in instalments inside the rounds, unthinned
+    }
+    int incl = len;
+#pragma unroll
+    for (int off = 1; off < kBeamPixels; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane < kBeamPixels) prefix[lane + 1] = incl;
+    if (lane == 0) prefix[0] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int total = __builtin_amdgcn_readfirstlane(prefix[kBeamPixels]);
+    for (int base = 0; base < total; base += 8) {
+        const int s = base + (lane >> 3), q = lane & 7;
+        bool keep = false;
+        int32_t* entry = beam_cand;
+        if (s < total) {
+            int j = 0;
+#pragma unroll
+            for (int k = 1; k < kBeamPixels; k++)
+                if (s >= prefix[k]) j = k;
+            entry = beam_cand + (j * kBeamCands + (s - prefix[j])) * 3;
+            const uint32_t code = (uint32_t)~entry[0];
+            if (q <= (int)(code & 7u)) {
+                const int32_t* st = beam_state + j * kBeamStateDwords;
+                const float dx = __int_as_float(st[22]), dy = __int_as_float(st[23]), dz = __int_as_float(st[24]);
+                const float err_d = kErr * sqrtf(dx * dx + dy * dy + dz * dz);
+                keep = !beam_rejects_face(tri32[(int32_t)(code >> 3) + q], __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]),
+                                          __int_as_float(st[19]), __int_as_float(st[20]), __int_as_float(st[21]), dx, dy, dz, err_d * radius, err_d);
+            }
+        }
+        const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
+        if (s < total && q == 0) entry[2] = (int32_t)((kept >> (lane & 56)) & 0xffull);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// A sample's search state over the instalments of its pixel's list.
+struct BeamHit {
+    bool hit;
+    double tmax;   // search limit: the closest hit so far
+    float tmax32;  // the same in the bundle's frame, rounded up
+    int prim;      // leaf-order position of the face hit
+    double t, u, v;
+};
+
+// The faces of n listed leaves (those their masks name) against this lane's ray; the list is the same for all lanes (read once, through LDS
+// broadcasts, into SGPRs) and so are the faces, which come through the scalar cache as in mesh_collide_packet.  f: the ray's
+// float32 origin in the bundle's frame, (o + d * T) - mesh centre.  Must be entered by the lanes of a wave together.
+// minima: the distances are suffix minima (beam_suffix_min), so the first entry beyond every lane's hit ends the search.
+RT_DEV void beam_test(const DScene& sc, const DMesh& m, const Ray& r, const FastRay& f, float dx, float dy, float dz, float err_r, float err_d,
+                      double T, const int32_t* cand, int n, bool minima, double tmin, BeamHit& bh, VisitCounts& cnt) {
+    const double* pos = sc.prim_pos + m.prim_off * 9;
+    const Tri32* tri32 = sc.prim_tri32 + m.prim_off;
+    for (int c = 0; c < n; c++) {
+        uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane(cand[3 * c + 2]);
+        if (mask == 0) continue;  // no face of this leaf can be hit by any ray of the bundle
+        const float tb = __int_as_float(__builtin_amdgcn_readfirstlane(cand[3 * c + 1]));
+        if (__builtin_amdgcn_ballot_w64(tb <= bh.tmax32) == 0) {  // the leaf begins beyond every lane's hit
+            if (minima) break;
+            continue;
+        }
+        const int32_t first = (int32_t)((uint32_t)~__builtin_amdgcn_readfirstlane(cand[3 * c]) >> 3);
+        RT_STAT(2, 1);
+        for (; mask != 0; mask &= mask - 1) {
+            const int32_t face = first + (__builtin_ffs((int)mask) - 1);
+            const Tri32 t32 = load_tri32_scalar(tri32, face);
+            const bool maybe = tb <= bh.tmax32 && !tri32_rejects(t32, f, dx, dy, dz, err_r, err_d);
+            RT_STAT(3, 1);
+            if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+            RT_STAT(4, 1);
+            if (maybe) {
+                cnt.prims++;
+                const RT_CONST_AS double* p = (const RT_CONST_AS double*)(pos + (int64_t)face * 9);
+                const V3 p0 = mk(p[0], p[1], p[2]), p1 = mk(p[3], p[4], p[5]), p2 = mk(p[6], p[7], p[8]);
+                double t, u, v;
+                // equal distances: the face latest in leaf order wins, as in mesh_collide_packet
+                if (mt_core(r, p0, p1, p2, 1e-8, tmin, bh.tmax, t, u, v) && !(bh.hit && t == bh.t && face < bh.prim)) {
+                    bh.hit = true;
+                    bh.tmax = t;
+                    bh.tmax32 = up32(t - T);
+                    bh.prim = face;
+                    bh.t = t; bh.u = u; bh.v = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace rt

@@ -18,7 +18,8 @@ struct PassDesc {
     int32_t max_depth;
     int32_t log2_s;                 // primary launch: 2^log2_s lanes of a wave trace samples of the same pixel
     int32_t block_px;               // primary launch: pixels of an 8x8 tile per work item (power of two >= 64 >> log2_s)
-    int32_t acc_offset, pad0;       // primary launch: where the pixels' running sums start in dynamic LDS, in dwords (set by launch_primary)
+    int32_t acc_offset;             // primary launch: where the pixels' running sums start in dynamic LDS, in dwords (set by launch_primary)
+    int32_t beam_offset;            // ... and where the pixel beams' lists and walk states start (set by launch_primary)
     int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group
     int64_t n_pixels;               // tiles * 64 = pixels (threads) of this pass
     uint32_t seed_lo, seed_hi;
@@ -53,8 +54,11 @@ struct RayStripeCounts {
 };
 
 // cam and q point to DEVICE copies of the structs
+// beam: the caller has an orthographic camera and wants the pixel-beam kernel; used when the scene and the pass allow it
+// (fast mode, a single untransformed mesh, 64 lanes per pixel, at most beam_pixels_max() pixels per item).
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
-                    double* film, hipStream_t s);
+                    double* film, hipStream_t s, bool beam = false);
+int beam_pixels_max();
 // tracePath for the first n.n[s] rays of every stripe s of rays[in]: closest hit, Material.Resolve, children appended to
 // rays[1 - in], lit surface points to q.surfs, emission to the film.  Scenes with a mesh: k_walk (closest hits into
 // q.hits, lanes refilled as their rays finish) then k_shade; scenes without: one fused launch (k_trace).

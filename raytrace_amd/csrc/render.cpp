@@ -546,6 +546,9 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     int lanes_override = -1;   // RT_LOG2_LANES / RT_ITEM_RAYS: tuning knobs of the primary launch
     int64_t item_rays = 512;
     if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
+    // Pixel beams (one tree walk per pixel instead of one per 64 samples, see dev_bvh.h): parallel rays through one mesh.
+    const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC && !getenv("RT_NO_BEAM");
+    if (beam) item_rays = 2048;  // a lane walks for each pixel of an item: eight pixels keep eight lanes busy in that phase
     if (const char* e = getenv("RT_ITEM_RAYS")) item_rays = std::max(1, atoi(e));
     for (int s0 = s_first; s0 < s_end;) {
         // a pass covers all tiles for a run of samples when that fits, else a run of tiles for one sample
@@ -590,6 +593,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 // pixels per item: about item_rays rays (512: smaller items shorten the tail of a launch, 2-3 % on an eighth of a 4K frame), at least what the wave traces at a time, at most the tile
                 int block = 64 >> log2_s;
                 while (block < 64 && (int64_t)block * s_count < item_rays) block <<= 1;
+                if (beam && log2_s == 6) block = std::min(block, beam_pixels_max());
                 pass.block_px = block;
             }
             pass.tile_begin = t0;
@@ -606,7 +610,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 HIP_TRY(events.next(&ev));
                 HIP_TRY(hipEventRecord(ev->a, stream));
             }
-            launch_primary(rep.dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream);
+            launch_primary(rep.dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream, beam);
             if (pass.order) culled_rays += w.culled_pixels * (uint64_t)s_count;  // tiles the schedule leaves out: nothing to trace
             if (timed) HIP_TRY(hipEventRecord(ev->b, stream));
             HIP_TRY(hipGetLastError());
@@ -726,6 +730,10 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
         const double w = ps[0] ? (double)ps[0] : 1.0, rounds = ps[10] ? (double)ps[10] : 1.0;
         fprintf(stderr, "[rt] packet walks %llu: per walk %.2f inner nodes, %.2f leaves, %.2f float32 face tests, %.2f float64 face tests, %.2f pops, %.2f pushes\n",
                 ps[0], ps[1] / w, ps[2] / w, ps[3] / w, ps[4] / w, ps[5] / w, ps[6] / w);
+        if (getenv("RT_DEBUG_BEAM"))
+            fprintf(stderr, "[rt] pixel beams: %llu pixels walked, %.1f inner nodes and %.2f leaves listed each, %.2f %% with a list longer than one instalment (%llu instalments inside rounds); "
+                            "per round %.2f leaves looked at, %.2f float32 face tests, %.2f float64; beam walks %.1f %% of all round cycles\n",
+                    ps[0], ps[1] / w, ps[6] / w, 100.0 * ps[5] / w, ps[7], ps[2] / rounds, ps[3] / rounds, ps[4] / rounds, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0);
         fprintf(stderr, "[rt] wave rounds %llu: %.0f cycles each on average; walks %.0f cycles each (%.0f of them in leaves), %.1f %% of all round cycles\n",
                 ps[10], ps[9] / rounds, ps[8] / w, ps[11] / w, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0);
         unsigned long long ts[64];

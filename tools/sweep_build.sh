@@ -8,7 +8,7 @@ for spec in "$@"; do
   set -- $spec
   name=$1; shift
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -munsafe-fp-atomics \
-      "$@" -o ../variants/librt_hip_${name}.so rt_api.cpp render.cpp kernels.hip bvh_build.cpp obj_scan.cpp &
+      "$@" -o ../variants/librt_hip_${name}.so rt_api.cpp render.cpp kernels.hip bvh_build.cpp obj_scan.cpp scene_json.cpp &
 done
 wait
 ls ../variants
