@@ -271,7 +271,7 @@ def main():
             "faces_per_ray": base["faces_per_ray"], "rays_per_launch": my_rays / max(float(trav_launches), 1.0),
             "avg_launch_ms": 1e3 * avg_launch_s, "miss_fraction": base["miss_fraction"],
             "note": "algorithmic bytes price every box and face test of the reference's left-first walk as an HBM access; the kernel "
-                    "walks a mesh once per 64 rays (wave packet, nodes through the scalar cache) and the scene (about 340 MB) sits in "
+                    "walks the mesh once per PIXEL (the bundle of the pixel's parallel rays; its samples then test only the faces listed) and the scene (about 340 MB) sits in "
                     "L2 and the 256 MB memory-side cache, so frac exceeds 1 and says nothing about HBM: hbm_counter_frac is the "
                     "measured HBM share, and the bound that limits the kernel is vector instruction issue (roofline_valu)",
         }

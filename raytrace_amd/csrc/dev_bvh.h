@@ -949,10 +949,10 @@ RT_DEV void beam_cull_item(const Tri32* tri32, float radius, int32_t* beam_state
 // A sample's search state over the instalments of its pixel's list.
 struct BeamHit {
     bool hit;
-    double tmax;   // search limit: the closest hit so far
-    float tmax32;  // the same in the bundle's frame, rounded up
+    float tmax32;  // the search limit (t) in the bundle's frame, rounded up
     int prim;      // leaf-order position of the face hit
-    double t, u, v;
+    double t;      // the closest hit so far; before the first one, the search limit
+    double u, v;
 };
 
 // The faces of n listed leaves (those their masks name) against this lane's ray; the list is the same for all lanes (read once, through LDS
@@ -986,9 +986,8 @@ RT_DEV void beam_test(const DScene& sc, const DMesh& m, const Ray& r, const Fast
                 const V3 p0 = mk(p[0], p[1], p[2]), p1 = mk(p[3], p[4], p[5]), p2 = mk(p[6], p[7], p[8]);
                 double t, u, v;
                 // equal distances: the face latest in leaf order wins, as in mesh_collide_packet
-                if (mt_core(r, p0, p1, p2, 1e-8, tmin, bh.tmax, t, u, v) && !(bh.hit && t == bh.t && face < bh.prim)) {
+                if (mt_core(r, p0, p1, p2, 1e-8, tmin, bh.t, t, u, v) && !(bh.hit && t == bh.t && face < bh.prim)) {
                     bh.hit = true;
-                    bh.tmax = t;
                     bh.tmax32 = up32(t - T);
                     bh.prim = face;
                     bh.t = t; bh.u = u; bh.v = v;

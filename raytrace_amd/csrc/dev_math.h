@@ -61,6 +61,16 @@ RT_HD bool bad3(V3 a) {  // IsNaN || IsInf, r3/vec.go:106-113
 // ---- random streams (stand in for phys/rand.go's math/rand wrapper) -------------------------
 // One Philox4x32-10 stream per ray, keyed by the seed, counted by (pixel, sample, path, draw/2).
 
+// n / d in three instructions when r = 1 / d is at hand: q0 = RN(n r) is within an ulp of the quotient, the remainder
+// n - q0 d is exact in a fused multiply-add, and RN(q0 + rem r) is the correctly rounded quotient (Markstein's theorem;
+// r must be the correctly rounded reciprocal, everything in the normal range).  The result is bit for bit the IEEE
+// division the reference performs.
+RT_HD double div_by(double n, double d, double r) {
+    const double q0 = n * r;
+    const double rem = __builtin_fma(-q0, d, n);
+    return __builtin_fma(rem, r, q0);
+}
+
 RT_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {

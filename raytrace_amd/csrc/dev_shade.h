@@ -60,7 +60,9 @@ RT_DEV V3 image_at(const DScene& sc, const rt_texture& tx, double u, double v) {
         int iy = (int)round(y);
         texel16(im, ix, iy, c);
     }
-    return mk((double)c[0] / 65535.0, (double)c[1] / 65535.0, (double)c[2] / 65535.0);
+    // c / 65535.0 (texture_image.go:183-187), see div_by: exact for every 16-bit c
+    const double r65535 = 1.0 / 65535.0;
+    return mk(div_by((double)c[0], 65535.0, r65535), div_by((double)c[1], 65535.0, r65535), div_by((double)c[2], 65535.0, r65535));
 }
 
 RT_DEV V3 texture_at(const DScene& sc, int tex, double u, double v) {

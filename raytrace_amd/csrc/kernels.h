@@ -27,7 +27,8 @@ struct PassDesc {
     // `order` set, queue k hands out order[queue_off[k] + i], i < queue_len[k] (tile numbers, costliest
     // first); without it, its tiles in ascending order.  With `cost` set, every work item adds the clock ticks
     // it took to cost[tile].
-    int32_t max_waves, pad1;        // primary launch: at most this many persistent waves (the queue stripes are sized for them)
+    int32_t max_waves;              // primary launch: at most this many persistent waves (the queue stripes are sized for them)
+    int32_t cull_pixels;            // pixel beams: a pixel whose bundle of rays misses the mesh is settled without generating its rays (they are counted)
     const int32_t* order;
     uint32_t* cost;
     uint32_t queue_off[8], queue_len[8];

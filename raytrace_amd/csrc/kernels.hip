@@ -528,7 +528,8 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // for beam_cull_item.
 template <int MODE, bool MESH_ONLY, bool SHADE, bool BEAM>
 RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, double* __restrict__ film, long long v,
-                         uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left, uint32_t& rot, VisitCounts& vc) {
+                         uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, uint32_t& rot,
+                         VisitCounts& vc) {
     const int lanes_s = 1 << pass.log2_s;       // lanes (= samples in flight) per pixel
     const int px_per_iter = 64 >> pass.log2_s;  // pixels a wave traces at a time
     const int my_px = p >> pass.log2_s, my_s = p & (lanes_s - 1);
@@ -538,6 +539,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
     const int w = (int)(tile & 63);
     const int tile_x = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8;
     const int tile_y = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8;
+    const double inv_dx = 1.0 / (double)pass.dx, inv_dy = 1.0 / (double)pass.dy;  // for div_by: the divisions of render.go:202-210
     int32_t* const beam_cand = dyn_lds + pass.beam_offset;
     int32_t* const beam_state = beam_cand + kBeamPixels * kBeamCands * 3;
     if (BEAM) {
@@ -610,6 +612,12 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
             beam_long = (found & 0x100) != 0;
             beam_T = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[11]) << 32) |
                                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[10])));
+            if (pass.cull_pixels && found == 0) {  // nothing listed: no ray through this pixel can hit, whatever its jitter
+                n_total += (uint32_t)pass.sample_count;
+                n_left += (uint32_t)pass.sample_count;
+                n_culled += (uint32_t)pass.sample_count;
+                continue;
+            }
         }
         for (int round = 0; round < rounds; round++) {
 #ifdef RT_VISIT_STATS
@@ -632,13 +640,18 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                 Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(yv * pass.dx + lxv), (uint32_t)s, 1u, 0u};
                 double fs, ft;
                 if (pass.spp == 1) {  // render.go:202-210
-                    fs = ((double)lxv + 0.5) / (double)pass.dx;
-                    ft = ((double)yv + 0.5) / (double)pass.dy;
+                    fs = div_by((double)lxv + 0.5, (double)pass.dx, inv_dx);
+                    ft = div_by((double)yv + 0.5, (double)pass.dy, inv_dy);
                 } else {
-                    fs = ((double)lxv + rng.float64()) / (double)pass.dx;
-                    ft = ((double)yv + rng.float64()) / (double)pass.dy;
+                    fs = div_by((double)lxv + rng.float64(), (double)pass.dx, inv_dx);
+                    ft = div_by((double)yv + rng.float64(), (double)pass.dy, inv_dy);
                 }
-                r = camera_cast(cam, fs, ft, rng);
+                if (BEAM) {  // the camera is orthographic (camera_orthographic.go:24-46); its direction is the same for every lane
+                    r.o = (ld3(cam.from) + ld3(cam.u) * (cam.fov_w * (fs - 0.5))) + ld3(cam.v) * (cam.fov_h * (ft - 0.5));
+                    r.d = ld3(cam.dir);
+                } else {
+                    r = camera_cast(cam, fs, ft, rng);
+                }
 #ifdef RT_VISIT_STATS
                 RT_STAT(13, clock64() - round_t0);
 #endif
@@ -658,15 +671,14 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
             if (BEAM) {
                 const DMesh& m = sc.meshes[sc.nodes[0].index];
                 const bool sound = traced && !(bad3(r.o) || bad3(r.d));  // render.go:147-150
-                BeamHit bh{false, kMaxFloat, __builtin_inff(), 0, 0, 0, 0};
+                BeamHit bh{false, __builtin_inff(), 0, kMaxFloat, 0, 0};
                 FastRay f{};
-                float dxf = 0, dyf = 0, dzf = 0, err_d = 0, err_r = 0;
+                // every ray of an orthographic camera has the camera's direction (camera_orthographic.go:44)
+                const float dxf = (float)cam.dir[0], dyf = (float)cam.dir[1], dzf = (float)cam.dir[2];
+                const float err_d = kErr * sqrtf(dxf * dxf + dyf * dyf + dzf * dzf), err_r = err_d * m.radius;
                 if (sound) {
                     const V3 ol = (r.o + r.d * beam_T) - ld3(m.center);
                     f.ox = (float)ol.x; f.oy = (float)ol.y; f.oz = (float)ol.z;
-                    dxf = (float)r.d.x; dyf = (float)r.d.y; dzf = (float)r.d.z;
-                    err_d = kErr * sqrtf(dxf * dxf + dyf * dyf + dzf * dzf);
-                    err_r = err_d * m.radius;
                 }
                 bool walking = beam_long;  // wave-uniform
                 if (walking && p == pb) beam_setup(cam, pass.dx, pass.dy, m, lx, y, px_state);  // this round's walk starts over
@@ -764,7 +776,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
     const int64_t n_tiles = pass.n_pixels >> 6;
     const uint32_t n_sub = 64u / (uint32_t)pass.block_px;  // items per tile
     const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
-    uint32_t n_total = 0, n_left = 0;
+    uint32_t n_total = 0, n_left = 0, n_culled = 0;
     uint32_t rot = blockIdx.x;  // stripe of the append queues this wave's next round writes to
     VisitCounts vc{0, 0};
     // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
@@ -802,13 +814,14 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         const long long t_start = pass.cost ? clock64() : 0;
         sub = __shfl(sub, 0, 64);
         primary_item<MODE, MESH_ONLY, SHADE, BEAM>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
-                                             reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left, rot, vc);
+                                             reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left, n_culled, rot, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
     if (p == 0) {  // the tallies are per wave already
         Counters::Tally& t = counters->tally[blockIdx.x & (kTallyStripes - 1)];
         if (n_total) atomicAdd(&t.total, (unsigned long long)n_total);
         if (n_left) atomicAdd(&t.left, (unsigned long long)n_left);
+        if (n_culled) atomicAdd(&t.culled, (unsigned long long)n_culled);
     }
     report_overflow(counters, vc);
 }

@@ -599,6 +599,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
             pass.tile_begin = t0;
             pass.n_pixels = nt * 64;
             pass.max_waves = sc->all_terminal ? 0 : (int32_t)w.primary_waves;  // nothing is queued when every material only emits
+            pass.cull_pixels = want_cull ? 1 : 0;
             const bool whole = t0 == 0 && nt == tiles_total;
             pass.order = (want_order && w.order_valid && whole) ? w.tile_order : nullptr;
             pass.cost = (pilot && whole) ? w.tile_cost : nullptr;
@@ -754,9 +755,13 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
 #endif
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        uint64_t total = launched_rays, exceeded = 0, left = 0;
-        for (const Counters::Tally& t : host.tally) { total += t.total; exceeded += t.exceeded; left += t.left; }
-        stats->total_rays = total + culled_rays;  // rays of culled tiles count as traced and as having left the scene
+        uint64_t total = launched_rays, exceeded = 0, left = 0, culled_in_kernel = 0;
+        for (const Counters::Tally& t : host.tally) { total += t.total; exceeded += t.exceeded; left += t.left; culled_in_kernel += t.culled; }
+        // pixels the primary kernel itself settled without generating their rays move from its tallies to the culled ones
+        total -= culled_in_kernel;
+        left -= culled_in_kernel;
+        culled_rays += culled_in_kernel;
+        stats->total_rays = total + culled_rays;  // rays of culled tiles and pixels count as traced and as having left the scene
         stats->rays_exceeded_depth = exceeded;
         stats->rays_left_scene = left + culled_rays;
         stats->shadow_rays = shadow_rays;

@@ -175,6 +175,7 @@ struct Counters {
         unsigned long long total;     // RenderStats (render.go:38-45): rays counted without being launched (children cut or invalid)
         unsigned long long exceeded;
         unsigned long long left;
+        unsigned long long culled;    // camera rays counted (in total and left) without being generated: their pixel's bundle of rays cannot reach the scene
     } tally[kTallyStripes];
     struct alignas(128) Cursor {
         unsigned int v;

@@ -10,8 +10,12 @@ CONFIGS = {
     "teapot": lambda: scenes.teapot(dx=1920, dy=1080, spp=32),
     "material": lambda: scenes.material(dx=1024, dy=1024, spp=32),
     "scan_lit": lambda: scenes.scan(level=7, dx=1920, dy=1080, spp=16, tex_size=1024, lit=True),
+    # 21 M faces: 2.5 GB of float64 vertices + 1 GB of float32 faces + 1.3 GB of nodes, far beyond L2 + the 256 MB memory-side
+    # cache; Lambertian + a point light, so every generation after the first is incoherent
+    "scan_big": lambda: scenes.scan(level=10, dx=1920, dy=1080, spp=16, tex_size=1024, lit=True),
+    "scan_big_emit": lambda: scenes.scan(level=10, dx=3840, dy=2160, spp=64, tex_size=4096),
 }
-names = sys.argv[1:] or list(CONFIGS)
+names = sys.argv[1:] or [n for n in CONFIGS if not n.startswith('scan_big')]
 for name in names:
     sc = CONFIGS[name]()
     with phys.DeviceScene(sc) as dev:
