@@ -376,6 +376,38 @@ def test_small_queues_park_rays_and_give_the_same_image(name, monkeypatch):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
 
 
+def test_overflow_pool_follows_a_deeper_later_render(monkeypatch):
+    """MaxRayDepth is an option of the call: a scene first rendered at depth 2 and then at depth 10 with 4096-path queues needs
+    a larger overflow pool the second time, and must give what a fresh handle gives."""
+    monkeypatch.setenv("RT_QUEUE_RAYS", "4096")
+    sc = scenes.material(dx=64, dy=64, spp=8, tex_size=(40, 36))
+    o2 = phys.RenderOptions(sc.RenderOptions.Seed, 8, 2, 64, 64)
+    o10 = phys.RenderOptions(sc.RenderOptions.Seed, 8, 10, 64, 64)
+    with phys.DeviceScene(sc) as dev:
+        dev.render(sc.Camera[0], o2)
+        deep = dev.render(sc.Camera[0], o10)
+    with phys.DeviceScene(sc) as fresh:
+        want = fresh.render(sc.Camera[0], o10)
+    for k in ("TotalRays", "RaysLeftScene", "RaysExceededDepth", "ShadowRays"):
+        assert getattr(deep.Stats, k) == getattr(want.Stats, k), k
+    assert deep.Stats.TotalRays > 2 * 64 * 64 * 8
+    diff = np.abs(deep.Image.astype(int) - want.Image.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+
+
+def test_more_lights_than_a_launch_can_address_are_refused():
+    lights = [phys.PointLight((float(i), 0.0, 5.0), (1.0, 1.0, 1.0)) for i in range(2048)]
+    sc = phys.Scene(Camera=[phys.OrthographicCamera((0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 2.0, 2.0)],
+                    Node=[phys.Node("s", phys.Sphere((0.0, 0.0, 0.0), 1.0), phys.Lambertian(phys.TextureUniform((0.5, 0.5, 0.5))))],
+                    Light=lights, RenderOptions=phys.RenderOptions(0, 1, 2, 8, 8))
+    with pytest.raises(RuntimeError, match="lights"):
+        phys.DeviceScene(sc)
+    sc.Light = lights[:2047]
+    with phys.DeviceScene(sc) as dev:
+        art = dev.render(sc.Camera[0], sc.RenderOptions)
+    assert art.Stats.ShadowRays > 0
+
+
 def test_three_cameras_on_one_scene_handle_match_the_oracle(ob):
     # The animation loop keeps the scene resident and changes only the camera (example/charuco/main.go:259-339).  The
     # cost-ordered tile schedule and the occupancy map are cached per camera: 3072 tiles x 32 samples keeps both live,

@@ -117,3 +117,27 @@ def test_animated_camera_resolves_on_the_host():  # camera_animated.go:53-131
         phys.AnimatedCamera(None).Validate()
     with pytest.raises(ValueError, match="Period is zero"):
         phys.AnimatedCamera(orbit).WithTime(1.0)
+
+
+def test_three_instruction_division_is_the_ieee_quotient():
+    """The kernels divide by Dx, Dy and 65535 as q0 = n*r, q = fma(fma(-q0, d, n), r, q0) with r = 1/d (div_by in
+    dev_math.h).  Emulated here with exact rationals (a fused multiply-add rounds once): the result must be the correctly
+    rounded quotient, i.e. what the reference's plain division gives (render.go:202-210, texture_image.go:183-187)."""
+    import random
+    from fractions import Fraction as F
+
+    def div_by(n, d):
+        r = 1.0 / d
+        q0 = n * r
+        rem = float(F(n) - F(q0) * d)
+        return float(F(q0) + F(rem) * F(r))
+
+    for c in range(65536):
+        assert div_by(float(c), 65535) == c / 65535.0
+    rng = random.Random(7)
+    for d in (1, 3, 41, 67, 96, 1080, 1920, 2160, 3840, 4096, 65535, 1000003):
+        for _ in range(3000):
+            n = float(rng.randrange(0, d)) + rng.getrandbits(53) / 2.0 ** 53
+            assert div_by(n, d) == n / d, (n, d)
+        for x in range(min(d, 500)):
+            assert div_by(x + 0.5, d) == (x + 0.5) / d
