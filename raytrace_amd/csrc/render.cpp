@@ -120,16 +120,23 @@ hipError_t copy_rays(const RayQ& dst, uint64_t dst_at, const RayQ& src, uint64_t
     return e;
 }
 
-int ensure_work(const rt_scene* sc, Replica& rep) {
-    if (rep.work) return RT_OK;
+// want_paths: the camera paths of the render about to run (pixels of this device's share x samples of the call).  The
+// queues of a scattering scene cost 650 bytes per path of a launch (21 GB at the default of 2^25 paths), so they are
+// sized for the frame at hand, between 2^18 and 2^25 paths, and grow when a later frame needs more: a host that keeps
+// many small scenes alive does not pay for a 4K frame in each.  RT_QUEUE_RAYS fixes the size instead.
+int ensure_work(const rt_scene* sc, Replica& rep, uint64_t want_paths) {
+    size_t q_want = (size_t)1 << 18;
+    while (q_want < ((size_t)1 << 25) && q_want < want_paths) q_want <<= 1;
+    if (std::getenv("RT_QUEUE_RAYS")) q_want = env_size("RT_QUEUE_RAYS", (size_t)1 << 25);
+    if (q_want < 64 * 64) q_want = 64 * 64;
+    if (rep.work && (sc->all_terminal || rep.work->q >= q_want)) return RT_OK;  // a scene that never shades never queues
     // built aside and published only when complete: a failed allocation must not leave half-made queues behind
     struct Holder {
         WorkBuffers* w = new WorkBuffers();
         ~Holder() { destroy_work(w); }
     } hold;
     WorkBuffers* w = hold.w;
-    w->q = (uint32_t)env_size("RT_QUEUE_RAYS", (size_t)1 << 25);
-    if (w->q < 64 * 64) w->q = 64 * 64;
+    w->q = (uint32_t)q_want;
     const size_t q = w->q;
     char *rays0 = nullptr, *rays1 = nullptr, *surfs = nullptr, *hits = nullptr;
     // a scene that never shades needs none of the queues (kernels still get valid pointers)
@@ -164,6 +171,18 @@ int ensure_work(const rt_scene* sc, Replica& rep) {
     HIP_TRY(w->mem.alloc(1, &w->d_queues));
     HIP_TRY(w->mem.alloc(1, &w->d_camera));
     HIP_TRY(hipMemcpy(w->d_queues, &w->queues, sizeof(Queues), hipMemcpyHostToDevice));
+    if (rep.work) {  // larger queues replace smaller ones: what does not depend on their size moves over
+        WorkBuffers* old = rep.work;
+        for (int k = 0; k < 2; k++) std::swap(w->frame[k], old->frame[k]);
+        std::swap(w->tile_cost, old->tile_cost);
+        std::swap(w->tile_order, old->tile_order);
+        std::swap(w->order_tiles, old->order_tiles);
+        std::swap(w->order_key, old->order_key);
+        std::swap(w->order_valid, old->order_valid);
+        std::swap(w->culled_pixels, old->culled_pixels);
+        for (int k = 0; k < 8; k++) { std::swap(w->queue_off[k], old->queue_off[k]); std::swap(w->queue_len[k], old->queue_len[k]); }
+        destroy_work(old);
+    }
     rep.work = w;
     hold.w = nullptr;
     return RT_OK;
@@ -414,7 +433,7 @@ WorkBuffers* static_work_for(int device, int64_t tiles_total) {
 }
 
 int scene_film(const rt_scene* sc, Replica& rep, int dx, int dy, double** film, uint8_t** rgba, uint8_t** rgba_host, int slot) {
-    if (int rc = ensure_work(sc, rep)) return rc;
+    if (int rc = ensure_work(sc, rep, 0)) return rc;  // the render itself asks for the queues its frame needs
     WorkBuffers::Frame& w = rep.work->frame[slot & 1];
     const size_t px = (size_t)dx * dy;
     if (w.rgba_bytes < px * 4) {
@@ -461,10 +480,13 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     HIP_TRY(hipSetDevice(rep.device));
     DCamera cam;
     if (int rc = make_camera(*camera, cam)) return rc;
+    int rows_here = 0;
+    for (int r = 0; r < o->dy; r++)
+        if ((r / 16) % world == rank) rows_here++;
     if (static_work) {
         if (!sc->all_terminal)
             return fail(RT_ERR_UNSUPPORTED, "this scene scatters rays: its ray queues do not fit the static scratch (only scenes whose materials all just emit do)");
-    } else if (int rc = ensure_work(sc, rep)) {
+    } else if (int rc = ensure_work(sc, rep, (uint64_t)o->dx * (uint64_t)rows_here * (uint64_t)(o->sample_count > 0 ? o->sample_count : o->rays_per_pixel))) {
         return rc;
     }
     WorkBuffers& w = static_work ? *static_work : *rep.work;

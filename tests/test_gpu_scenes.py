@@ -395,6 +395,25 @@ def test_overflow_pool_follows_a_deeper_later_render(monkeypatch):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
 
 
+def test_queues_grow_when_a_later_frame_needs_more_paths():
+    """The ray queues are sized for the frame at hand (2^18 paths at least) and replaced by larger ones when a later frame of
+    the same handle has more; the image buffers and the handle stay the same."""
+    small = scenes.cornell(dx=32, dy=32, spp=4)
+    big = scenes.cornell(dx=640, dy=480, spp=2)  # 614 400 paths: beyond the first allocation
+    with phys.DeviceScene(small) as dev:
+        first = dev.render(small.Camera[0], small.RenderOptions)
+        grown = dev.render(big.Camera[0], big.RenderOptions)
+        again = dev.render(small.Camera[0], small.RenderOptions)
+    with phys.DeviceScene(big) as fresh:
+        want = fresh.render(big.Camera[0], big.RenderOptions)
+    for k in ("TotalRays", "RaysLeftScene", "RaysExceededDepth", "ShadowRays"):
+        assert getattr(grown.Stats, k) == getattr(want.Stats, k), k
+        assert getattr(again.Stats, k) == getattr(first.Stats, k), k
+    diff = np.abs(grown.Image.astype(int) - want.Image.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    assert np.abs(again.Image.astype(int) - first.Image.astype(int)).max() <= 1
+
+
 def test_more_lights_than_a_launch_can_address_are_refused():
     lights = [phys.PointLight((float(i), 0.0, 5.0), (1.0, 1.0, 1.0)) for i in range(2048)]
     sc = phys.Scene(Camera=[phys.OrthographicCamera((0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 2.0, 2.0)],
