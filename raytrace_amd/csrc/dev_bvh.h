@@ -504,9 +504,16 @@ RT_DEV void walk_round(const DScene& sc, WalkLane& w, int32_t node, double tmin,
     const uint32_t code = (uint32_t)~w.cur;
     const int32_t first = (int32_t)(code >> 3);
     const int32_t count = (int32_t)(code & 7u) + 1;
-    for (int32_t q = 0; q < count; q++) {
-        if (tri32_rejects(tri32[first + q], f, w.dx, w.dy, w.dz, w.err_r, w.err_d)) continue;
-        const double* p = pos + (int64_t)(first + q) * 9;
+    // The float32 pre-tests of the whole leaf first, then the float64 tests of the survivors: the lanes of a wave stand on
+    // different leaves, so with both in one loop the long float64 block would run in nearly every iteration for the few
+    // lanes whose face passed; apart, it runs as often as the lane with the most survivors needs (once or twice).
+    uint32_t pending = 0;
+    for (int32_t q = 0; q < count; q++)
+        if (!tri32_rejects(tri32[first + q], f, w.dx, w.dy, w.dz, w.err_r, w.err_d)) pending |= 1u << q;
+    while (pending != 0) {
+        const int32_t face = first + (__builtin_ffs((int)pending) - 1);
+        pending &= pending - 1;
+        const double* p = pos + (int64_t)face * 9;
         double t, u, v;
         if (mt_core(w.lr, ld3(p), ld3(p + 3), ld3(p + 6), 1e-8, tmin, best.t, t, u, v)) {
             if (ANY_HIT) {
@@ -514,10 +521,10 @@ RT_DEV void walk_round(const DScene& sc, WalkLane& w, int32_t node, double tmin,
                 w.cur = kFastEmpty;
                 return;
             }
-            if (!best.takes(t, node, first + q)) continue;
+            if (!best.takes(t, node, face)) continue;
             best.t = t;
             best.node = node;
-            best.leaf = first + q;
+            best.leaf = face;
             w.tmax32 = up32(t - w.t_shift);
         }
     }

@@ -569,7 +569,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     int64_t item_rays = 512;
     if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
     // Pixel beams (one tree walk per pixel instead of one per 64 samples, see dev_bvh.h): parallel rays through one mesh.
-    const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC && !getenv("RT_NO_BEAM");
+    const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC && !getenv("RT_NO_BEAM");
     if (beam) item_rays = 2048;  // a lane walks for each pixel of an item: eight pixels keep eight lanes busy in that phase
     if (const char* e = getenv("RT_ITEM_RAYS")) item_rays = std::max(1, atoi(e));
     for (int s0 = s_first; s0 < s_end;) {
