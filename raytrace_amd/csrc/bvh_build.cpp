@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <future>
 #include <limits>
 #include <memory>
@@ -349,6 +350,79 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
                     qn.q[k][a][1] = (uint16_t)std::min(65535.0, std::ceil(pmax) + 1.0);
                 }
             }
+        }
+    }
+
+    // Two levels per node.  Built without recursion (a work list of (binary node, slot to patch)): trees of scans are deep.
+    {
+        out.q4_nodes.clear();
+        out.q4_nodes.reserve(out.q_nodes.size() / 2 + 1);
+        struct Todo { int32_t bin; int32_t parent; int slot; int32_t depth; };
+        std::vector<Todo> todo;
+        todo.push_back({0, -1, 0, 1});
+        out.q4_depth = 1;
+        while (!todo.empty()) {
+            const Todo t = todo.back();
+            todo.pop_back();
+            const int32_t me = (int32_t)out.q4_nodes.size();
+            out.q4_nodes.emplace_back();
+            if (t.parent >= 0) out.q4_nodes[(size_t)t.parent].child[t.slot] = me;
+            out.q4_depth = std::max(out.q4_depth, t.depth);
+            Q4Node node;
+            int n = 0;
+            auto add = [&](const uint16_t (&q)[3][2], int32_t ref) {
+                std::memcpy(node.q[n], q, sizeof(node.q[n]));
+                node.child[n] = ref;
+                n++;
+            };
+            auto area = [&](int i) {
+                const double dx = (double)node.q[i][0][1] - node.q[i][0][0], dy = (double)node.q[i][1][1] - node.q[i][1][0],
+                             dz = (double)node.q[i][2][1] - node.q[i][2][0];
+                return dx * dy + dy * dz + dz * dx;
+            };
+            {
+                const QNode& b = out.q_nodes[(size_t)t.bin];
+                for (int k = 0; k < 2; k++)
+                    if (b.child[k] != kFastEmpty) add(b.q[k], b.child[k]);
+            }
+            // open the largest inner slot until the node is full (or holds leaves only): the big boxes are the ones most
+            // rays enter anyway, so their children belong one level up
+            for (;;) {
+                int pick = -1;
+                for (int i = 0; i < n; i++)
+                    if (node.child[i] >= 0 && (pick < 0 || area(i) > area(pick))) pick = i;
+                if (pick < 0) break;
+                const QNode& g = out.q_nodes[(size_t)node.child[pick]];
+                const int kids = (g.child[0] != kFastEmpty) + (g.child[1] != kFastEmpty);
+                if (n - 1 + kids > 4) break;
+                // the picked slot is replaced by the first child, the second (if any) goes to the end
+                bool placed = false;
+                for (int j = 0; j < 2; j++) {
+                    if (g.child[j] == kFastEmpty) continue;
+                    if (!placed) {
+                        std::memcpy(node.q[pick], g.q[j], sizeof(node.q[pick]));
+                        node.child[pick] = g.child[j];
+                        placed = true;
+                    } else {
+                        add(g.q[j], g.child[j]);
+                    }
+                }
+                if (!placed) {  // an inner node without children cannot be reached by any ray: drop the slot
+                    n--;
+                    std::memcpy(node.q[pick], node.q[n], sizeof(node.q[pick]));
+                    node.child[pick] = node.child[n];
+                }
+            }
+            for (int i = n; i < 4; i++) {
+                for (int a = 0; a < 3; a++) { node.q[i][a][0] = 65535; node.q[i][a][1] = 0; }
+                node.child[i] = kFastEmpty;
+            }
+            for (int i = 0; i < n; i++)
+                if (node.child[i] >= 0) {
+                    todo.push_back({node.child[i], me, i, t.depth + 1});
+                    node.child[i] = kFastEmpty;  // patched when the child is made
+                }
+            out.q4_nodes[(size_t)me] = node;
         }
     }
 

@@ -46,6 +46,16 @@ struct QNode {
 };
 static_assert(sizeof(QNode) == 32, "QNode layout");
 
+// Two levels of that tree in one 64-byte node: up to four (grand)children with their quantised boxes.  A walk that fetches
+// its nodes per lane is bound by the chain of dependent fetches, one per level; this halves the chain.  A child that is
+// a leaf (or whose own children are leaves) simply fills fewer slots; empty slots keep child == kFastEmpty and an
+// inverted box.  Inner references index this array.
+struct Q4Node {
+    uint16_t q[4][3][2];  // [slot][axis][0 = min, 1 = max]
+    int32_t child[4];
+};
+static_assert(sizeof(Q4Node) == 64, "Q4Node layout");
+
 // Float32 copy of a face for the conservative pre-test that runs before the float64
 // intersection: p0 relative to the mesh centre, the two edges, and their lengths (the
 // error bound of the pre-test scales with them).  48 bytes.
@@ -62,6 +72,8 @@ struct MeshBvh {
     std::vector<RefNode> ref_nodes;
     std::vector<FastNode> fast_nodes;
     std::vector<QNode> q_nodes;       // index for index the same tree as fast_nodes
+    std::vector<Q4Node> q4_nodes;     // the same tree, two levels per node
+    int32_t q4_depth = 1;             // levels of inner nodes of q4_nodes
     float grid_lo[3], grid_step[3];   // the grid of q_nodes, mesh frame
     std::vector<int32_t> prim_face;   // leaf order -> face index inside the mesh
     std::vector<double> prim_pos;     // leaf order, 9 float64 per face (P0, P1, P2)

@@ -422,7 +422,11 @@ RT_DEV bool walk_begin(const DMesh& m, const Ray& lr, double tmin, double tmax, 
     const float dlen = sqrtf(w.dx * w.dx + w.dy * w.dy + w.dz * w.dz);
     w.err_d = kErr * dlen;
     w.err_r = w.err_d * m.radius;
+#ifdef RT_WALK_BINARY
     w.node_base = (uint32_t)m.fast_off;
+#else
+    w.node_base = (uint32_t)m.q4_off;
+#endif
     w.prim_base = (uint32_t)m.prim_off;
     w.cur = 0;
     w.sp = 0;
@@ -508,6 +512,115 @@ RT_DEV void walk_round(const DScene& sc, WalkLane& w, int32_t node, double tmin,
     // different leaves, so with both in one loop the long float64 block would run in nearly every iteration for the few
     // lanes whose face passed; apart, it runs as often as the lane with the most survivors needs (once or twice).
     uint32_t pending = 0;
+    for (int32_t q = 0; q < count; q++)
+        if (!tri32_rejects(tri32[first + q], f, w.dx, w.dy, w.dz, w.err_r, w.err_d)) pending |= 1u << q;
+    while (pending != 0) {
+        const int32_t face = first + (__builtin_ffs((int)pending) - 1);
+        pending &= pending - 1;
+        const double* p = pos + (int64_t)face * 9;
+        double t, u, v;
+        if (mt_core(w.lr, ld3(p), ld3(p + 3), ld3(p + 6), 1e-8, tmin, best.t, t, u, v)) {
+            if (ANY_HIT) {
+                best.node = node;
+                w.cur = kFastEmpty;
+                return;
+            }
+            if (!best.takes(t, node, face)) continue;
+            best.t = t;
+            best.node = node;
+            best.leaf = face;
+            w.tmax32 = up32(t - w.t_shift);
+        }
+    }
+    pop_next();
+}
+
+// walk_round over the four-wide nodes (Q4Node): the same search with half as many dependent node fetches.  The (up to
+// four) children a ray reaches are sorted by entry distance; the nearest is visited next, the others are pushed farthest
+// first.  WalkLane::node_base must then be the mesh's first Q4Node.
+template <bool ANY_HIT, int RING>
+RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin, BestHit& best, const WalkStack& st, bool& overflow) {
+    const Q4Node* nodes = sc.q4_nodes + w.node_base;
+    const double* pos = sc.prim_pos + (size_t)w.prim_base * 9;
+    const Tri32* tri32 = sc.prim_tri32 + w.prim_base;
+    const float inf32 = __builtin_inff();
+    FastRay f;  // what the face pre-test reads of it
+    f.ox = w.ox; f.oy = w.oy; f.oz = w.oz;
+    auto pop_next = [&]() {
+        w.cur = kFastEmpty;
+        while (w.sp > 0) {  // skipping subtrees that begin beyond the current hit
+            w.sp--;
+            int32_t ref, tbits;
+            if (RING == 0 || w.sp >= w.base) {
+                const int slot = RING ? (w.sp & (RING - 1)) : w.sp;
+                ref = st.lds[(2 * slot) * 64];
+                tbits = st.lds[(2 * slot + 1) * 64];
+            } else {  // the ring is empty: the next entry comes back from the spill area
+                const int2 e = st.spill[(size_t)w.sp * 64];
+                ref = e.x;
+                tbits = e.y;
+                w.base = w.sp;
+            }
+            if (__int_as_float(tbits) <= w.tmax32) { w.cur = ref; break; }
+        }
+    };
+    auto push = [&](int32_t ref, float t) {
+        if (w.sp < st.cap) {
+            if (RING != 0 && w.sp - w.base == RING) {  // the ring is full: its oldest entry moves to the spill area
+                const int old = w.base & (RING - 1);
+                st.spill[(size_t)w.base * 64] = int2{st.lds[(2 * old) * 64], st.lds[(2 * old + 1) * 64]};
+                w.base++;
+            }
+            const int slot = RING ? (w.sp & (RING - 1)) : w.sp;
+            st.lds[(2 * slot) * 64] = ref;
+            st.lds[(2 * slot + 1) * 64] = __float_as_int(t);
+            w.sp++;
+        } else {
+            overflow = true;  // the host sizes the stack from the deepest tree: cannot happen, but must not pass silently
+        }
+    };
+    while (w.cur >= 0) {
+#ifdef RT_VISIT_STATS
+        w.steps++;
+#endif
+        const Q4Node n = nodes[w.cur];
+        float tn[4];
+        int32_t ch[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const f32x2 x = __builtin_elementwise_fma(f32x2{(float)n.q[k][0][0], (float)n.q[k][0][1]}, f32x2{w.gax, w.gax}, f32x2{w.gbx, w.gbx});
+            const f32x2 y = __builtin_elementwise_fma(f32x2{(float)n.q[k][1][0], (float)n.q[k][1][1]}, f32x2{w.gay, w.gay}, f32x2{w.gby, w.gby});
+            const f32x2 z = __builtin_elementwise_fma(f32x2{(float)n.q[k][2][0], (float)n.q[k][2][1]}, f32x2{w.gaz, w.gaz}, f32x2{w.gbz, w.gbz});
+            const float tnear = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), w.tmin32));
+            const float tfar = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), w.tmax32));
+            ch[k] = n.child[k];
+            tn[k] = ((tnear <= tfar) && ch[k] != kFastEmpty) ? tnear : inf32;
+        }
+        auto order = [&](int a, int b) {  // tn[a] <= tn[b] afterwards
+            const bool sw = tn[b] < tn[a];
+            const float ta = sw ? tn[b] : tn[a], tb = sw ? tn[a] : tn[b];
+            const int32_t ca = sw ? ch[b] : ch[a], cb = sw ? ch[a] : ch[b];
+            tn[a] = ta; tn[b] = tb; ch[a] = ca; ch[b] = cb;
+        };
+        order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
+        if (tn[0] < inf32) {
+            if (tn[1] < inf32) {
+                if (tn[2] < inf32) {
+                    if (tn[3] < inf32) push(ch[3], tn[3]);
+                    push(ch[2], tn[2]);
+                }
+                push(ch[1], tn[1]);
+            }
+            w.cur = ch[0];
+        } else {
+            pop_next();
+        }
+    }
+    if (w.cur == kFastEmpty) return;
+    const uint32_t code = (uint32_t)~w.cur;
+    const int32_t first = (int32_t)(code >> 3);
+    const int32_t count = (int32_t)(code & 7u) + 1;
+    uint32_t pending = 0;  // pre-tests of the whole leaf first, then the float64 tests of the survivors (see walk_round)
     for (int32_t q = 0; q < count; q++)
         if (!tri32_rejects(tri32[first + q], f, w.dx, w.dy, w.dz, w.err_r, w.err_d)) pending |= 1u << q;
     while (pending != 0) {

@@ -41,7 +41,7 @@ struct Queues {
     Counters* counters;
     uint32_t ray_stripe_cap, surf_stripe_cap;  // entries per stripe; stripe s of a queue is [s * cap, (s + 1) * cap)
     uint32_t hit_stripe_cap;                   // a multiple of kClaim
-    int2* walk_spill;  // k_walk: what the LDS ring of a lane's walk stack cannot hold; wave w, entry i, lane l at [(w * stack_pairs + i) * 64 + l]
+    int2* walk_spill;  // k_walk: what the LDS ring of a lane's walk stack cannot hold; wave w, entry i, lane l at [(w * walk_cap + i) * 64 + l]
 };
 
 constexpr uint32_t kWalkWavesMax = 8192;  // persistent waves of k_walk at most (the hit queue has room for a partly filled block of each)

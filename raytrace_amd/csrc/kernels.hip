@@ -244,6 +244,8 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
         if (MODE == RT_MODE_FAST && nd.kind == RT_SHAPE_MESH) {
             double t, u, v;
             int p;
+            // (a four-wide any-hit walk was tried here and lost: neighbouring surface points send their shadow rays the same way,
+            // and this walk fetches a node the whole wave stands on once, through the scalar cache)
             if (mesh_collide_fast<true>(sc, sc.meshes[nd.index], r, kEps, dist, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt)) return true;
             continue;
         }
@@ -937,7 +939,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_walk(DScene sc, Queues q
     Counters* const C = q.counters;
     const int lane = (int)threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const WalkStack stack{dyn_lds + threadIdx.x, q.walk_spill + (size_t)blockIdx.x * (size_t)sc.stack_pairs * 64 + threadIdx.x, sc.stack_pairs};
+    const WalkStack stack{dyn_lds + threadIdx.x, q.walk_spill + (size_t)blockIdx.x * (size_t)sc.walk_cap * 64 + threadIdx.x, sc.walk_cap};
     // wave-uniform: the blocks of rays and of hit records this wave has reserved
     int in_stripe = (int)(blockIdx.x % (unsigned)n_stripes), drained = 0;
     uint32_t in_pos = 0, in_end = 0;
@@ -1093,7 +1095,11 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_walk(DScene sc, Queues q
             ws_lanes += __popcll(walking);
 #endif
             if (w.cur != kFastEmpty) {
+#ifdef RT_WALK_BINARY
                 walk_round<false, kWalkRing>(sc, w, walk_node, kEps, best, stack, vc.overflow);
+#else
+                walk_round4<false, kWalkRing>(sc, w, walk_node, kEps, best, stack, vc.overflow);
+#endif
                 if (w.cur == kFastEmpty && sc.n_walk_nodes > 1) {  // this tree is done: on to the next one the ray can reach
                     walk_k++;
                     next_walk(load_ray());

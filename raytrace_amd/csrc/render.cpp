@@ -161,7 +161,7 @@ int ensure_work(const rt_scene* sc, Replica& rep, uint64_t want_paths) {
     HIP_TRY(w->mem.alloc(kQueueStripes * hit_cap * kHitBytes, &hits));
     carve(w->queues.hits, hits, kQueueStripes * hit_cap);
     w->queues.hit_stripe_cap = (uint32_t)hit_cap;
-    if (rep.dev.n_meshes > 0 && !sc->all_terminal) HIP_TRY(w->mem.alloc((size_t)kWalkWavesMax * 64 * (size_t)rep.dev.stack_pairs, &w->queues.walk_spill));
+    if (rep.dev.n_meshes > 0 && !sc->all_terminal) HIP_TRY(w->mem.alloc((size_t)kWalkWavesMax * 64 * (size_t)rep.dev.walk_cap, &w->queues.walk_spill));
     HIP_TRY(w->mem.alloc(1, &w->queues.counters));
     carve(w->queues.rays[0], rays0, (size_t)w->ray_stripes * ray_cap);
     carve(w->queues.rays[1], rays1, (size_t)w->ray_stripes * ray_cap);

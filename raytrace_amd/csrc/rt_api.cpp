@@ -388,6 +388,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<RefNode> ref_nodes;
     std::vector<FastNode> fast_nodes;
     std::vector<QNode> q_nodes;
+    std::vector<Q4Node> q4_nodes;
+    int32_t walk_cap = 2;
     std::vector<double> prim_pos;
     std::vector<Tri32> prim_tri32;
     std::vector<int32_t> prim_face;
@@ -402,6 +404,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         DMesh& m = meshes[i];
         m.ref_off = (int64_t)ref_nodes.size();
         m.fast_off = (int64_t)fast_nodes.size();
+        m.q4_off = (int64_t)q4_nodes.size();
         m.prim_off = (int64_t)prim_face.size();
         m.face_off = (int64_t)d->meshes[i].first_face;
         std::memcpy(m.center, b.center, sizeof(m.center));
@@ -415,6 +418,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         ref_nodes.insert(ref_nodes.end(), b.ref_nodes.begin(), b.ref_nodes.end());
         fast_nodes.insert(fast_nodes.end(), b.fast_nodes.begin(), b.fast_nodes.end());
         q_nodes.insert(q_nodes.end(), b.q_nodes.begin(), b.q_nodes.end());
+        q4_nodes.insert(q4_nodes.end(), b.q4_nodes.begin(), b.q4_nodes.end());
+        walk_cap = std::max(walk_cap, std::max(b.fast_depth + 1, 3 * b.q4_depth + 1));
         prim_pos.insert(prim_pos.end(), b.prim_pos.begin(), b.prim_pos.end());
         prim_tri32.insert(prim_tri32.end(), b.prim_tri32.begin(), b.prim_tri32.end());
         prim_face.insert(prim_face.end(), b.prim_face.begin(), b.prim_face.end());
@@ -455,12 +460,13 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     sc->nodes = nodes;
     // RT_STACK_PAIRS: a test knob that gives the traversal stacks fewer entries than the deepest tree needs, to
     // exercise the overflow report (a render then fails with RT_ERR_DEVICE instead of returning a wrong image)
-    if (const char* e = std::getenv("RT_STACK_PAIRS")) stack_pairs = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("RT_STACK_PAIRS")) stack_pairs = walk_cap = std::max(1, std::atoi(e));
     DScene proto{};
     proto.n_walk_nodes = (int32_t)walk_nodes.size();
     proto.n_nodes = (int32_t)d->n_nodes;
     proto.n_lights = (int32_t)d->n_lights;
     proto.stack_pairs = stack_pairs;
+    proto.walk_cap = walk_cap;
     proto.n_meshes = (int32_t)d->n_meshes;
     {   // bounds of every node that holds a mesh (directly or under transforms): rays that miss them never walk a tree
         bool any = false;
@@ -502,6 +508,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         HIP_TRY(rep->mem.upload(ref_nodes, &dev.ref_nodes));
         HIP_TRY(rep->mem.upload(fast_nodes, &dev.fast_nodes));
         HIP_TRY(rep->mem.upload(q_nodes, &dev.q_nodes));
+        HIP_TRY(rep->mem.upload(q4_nodes, &dev.q4_nodes));
         HIP_TRY(rep->mem.upload(prim_pos, &dev.prim_pos));
         HIP_TRY(rep->mem.upload(prim_tri32, &dev.prim_tri32));
         HIP_TRY(rep->mem.upload(prim_face, &dev.prim_face));

@@ -64,6 +64,7 @@ struct DMesh {
     int32_t n_faces;
     int32_t pad2;
     float grid_lo[3], grid_step[3];  // the grid of this mesh's QNodes (mesh frame)
+    int64_t q4_off;    // first Q4Node
 };
 
 struct DImage {
@@ -82,6 +83,7 @@ struct DScene {
     const RefNode* ref_nodes;
     const FastNode* fast_nodes;
     const QNode* q_nodes;      // the same trees, quantised: index for index fast_nodes
+    const Q4Node* q4_nodes;    // the same trees, quantised, two levels per node (DMesh::q4_off)
     const double* prim_pos;    // 9 per prim, leaf order
     const Tri32* prim_tri32;   // leaf order
     const int32_t* prim_face;  // leaf order -> face index within its mesh
@@ -93,6 +95,7 @@ struct DScene {
     const double* node_box;  // per node: padded world-space bounds (min xyz, max xyz); fast mode skips a node the ray misses
     int32_t n_nodes, n_lights;
     int32_t stack_pairs;  // depth of the deepest fast tree + 1: capacity of the LDS traversal stack
+    int32_t walk_cap;     // entries a k_walk lane's stack can need: a four-wide node pushes up to three per level
     int32_t n_meshes;     // meshes in the scene (0: no tree walk anywhere, launches favour registers over occupancy)
     // Scenes that mix meshes with other shapes queue scattered rays in two classes: those that can reach a mesh (they
     // pass through walk_box, the bounds of all mesh nodes) and the others, so that the waves of the next launch hold
