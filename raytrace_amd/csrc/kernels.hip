@@ -43,7 +43,7 @@ extern __shared__ int32_t dyn_lds[];
 #define RT_PACKET_WAVES 4  // the same for the primary kernel of mesh-only scenes (wave-packet traversal)
 #endif
 #ifndef RT_PACKET_SHADE_WAVES
-#define RT_PACKET_SHADE_WAVES 4  // ... and when that kernel also runs Material.Resolve
+#define RT_PACKET_SHADE_WAVES 3  // ... and when that kernel also runs Material.Resolve (168 VGPRs; at 4 waves it spills 392 B per lane: scan-lit 4.55 -> 4.75 Grays/s)
 #endif
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 3  // k_trace, mesh-only scenes
@@ -56,6 +56,9 @@ extern __shared__ int32_t dyn_lds[];
 #endif
 #ifndef RT_DIRECT_WAVES
 #define RT_DIRECT_WAVES 3  // k_direct
+#endif
+#ifndef RT_FAST_SHADE_WAVES
+#define RT_FAST_SHADE_WAVES 2  // the primary kernel of scenes with analytic shapes when it also runs Material.Resolve (at 3 waves: 600 B of spills per lane; cornell and teapot +3 %)
 #endif
 #ifndef RT_FAST_WAVES
 #define RT_FAST_WAVES 3
@@ -768,7 +771,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
 // SHADE = false: the host has checked that every material only emits, so no hit ever needs Material.Resolve and
 // its code (and registers) is left out.
 template <int MODE, bool MESH_ONLY, bool SHADE, bool BEAM = false>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY ? (SHADE ? RT_PACKET_SHADE_WAVES : RT_PACKET_WAVES) : RT_FAST_WAVES) : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY ? (SHADE ? RT_PACKET_SHADE_WAVES : RT_PACKET_WAVES) : (SHADE ? RT_FAST_SHADE_WAVES : RT_FAST_WAVES)) : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
     // The camera and the queue descriptors are read through pointers where they are used: as by-value arguments
     // their ~100 dwords would sit in SGPRs for the whole kernel and push other scalars out into VGPR lanes.
     const DCamera& cam = *camp;
