@@ -570,7 +570,9 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
     // Pixel beams (one tree walk per pixel instead of one per 64 samples, see dev_bvh.h): parallel rays through one mesh.
     const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC && !getenv("RT_NO_BEAM");
-    if (beam) item_rays = 2048;  // a lane walks for each pixel of an item: eight pixels keep eight lanes busy in that phase
+    // a lane walks for each pixel of an item: eight pixels keep eight lanes busy in that phase; a device's share of a frame
+    // split over four or more devices is better off with four (the last items of a short launch weigh more)
+    if (beam) item_rays = tiles_total * 64 >= 3000000 ? 2048 : 1024;
     if (const char* e = getenv("RT_ITEM_RAYS")) item_rays = std::max(1, atoi(e));
     for (int s0 = s_first; s0 < s_end;) {
         // a pass covers all tiles for a run of samples when that fits, else a run of tiles for one sample
