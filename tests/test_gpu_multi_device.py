@@ -73,3 +73,22 @@ def test_three_replicas_and_the_callers_band_split_is_refused(two_devices):
         ro = phys.render_opts(sc.RenderOptions, band_rank=0, band_world=2)
         rc = lib.rt_render(dev.handle, C.byref(cd), C.byref(ro), img.ctypes.data_as(C.POINTER(C.c_uint8)), 800, None)
         assert rc == abi.RT_ERR_INVALID and b"several devices" in lib.rt_last_error()
+
+
+def test_frame_loop_and_beam_kernel_on_two_replicas(two_devices):
+    """rt_render_frames over a scene that lives on two devices, with enough samples per pass for the pixel-beam kernel: every
+    frame must be the single-device frame (rows are copied, so byte for byte)."""
+    from raytrace_amd import _lib
+    lib, devices = two_devices
+    sc = scenes.scan(level=5, dx=200, dy=136, spp=64, tex_size=128)
+    c0 = sc.Camera[0]
+    cams = [type(c0)(**{**c0.__dict__, "FOVHeight": c0.FOVHeight * (1 + 0.1 * f), "FOVWidth": c0.FOVWidth * (1 + 0.1 * f)}) for f in range(4)]
+    with phys.DeviceScene(sc) as dev:
+        one, st_one = dev.render_frames(cams, sc.RenderOptions)
+    _lib.init(lib, devices)
+    with phys.DeviceScene(sc) as dev:
+        two, st_two = dev.render_frames(cams, sc.RenderOptions)
+    assert np.array_equal(one, two)
+    for a, b in zip(st_one, st_two):
+        assert (a.TotalRays, a.RaysLeftScene) == (b.TotalRays, b.RaysLeftScene)
+    assert len({one[i].tobytes() for i in range(4)}) == 4
