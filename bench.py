@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on the einstein-scan configuration.
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): the scan stand-in mesh
+Workload (the configuration the headline metric is quoted on): the scan stand-in mesh
 (icosphere level 8, 1,310,720 faces; the real einstein.obj is not available), Emitter +
 4096^2 bilinear image texture, orthographic camera of example/scan, 3840x2160, 1024 rays per
 pixel, fast mode.  One "step" renders `--spp-step` consecutive sample indices of every pixel of

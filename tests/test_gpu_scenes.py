@@ -263,7 +263,7 @@ def test_obj_route_renders_the_same_image_as_the_direct_route(ob):
 
 
 def test_full_size_teapot_frame_properties():
-    """BASELINE configs[1] at its full size (1920x1080, 256 spp, metal mesh on a checkerboard, two lights), checked
+    """The teapot configuration at its full size (1920x1080, 256 spp, metal mesh on a checkerboard, two lights), checked
     through properties: counter identities, additivity over sample ranges and over row bands (float64 atomics
     add in a different order, hence the tolerance)."""
     import torch

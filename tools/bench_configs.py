@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of the other BASELINE configurations (stochastic materials: shade / light-loop / scattered-ray
+"""Throughput of the other benchmark configurations (stochastic materials: shade / light-loop / scattered-ray
 generations), fast mode, one GPU.  usage: bench_configs.py [name ...]"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The BASELINE configurations at their full sizes (teapot 1920x1080 @ 256 spp, material 2048x2048 @ 4096 spp), fast mode,
+"""The teapot and material configurations at their full sizes (teapot 1920x1080 @ 256 spp, material 2048x2048 @ 4096 spp), fast mode,
 one GPU: whole-frame time and rate.  usage: bench_full_configs.py [teapot] [material]"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
