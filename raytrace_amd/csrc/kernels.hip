@@ -172,6 +172,37 @@ RT_DEV bool node_box_reachable(const double* b, const Ray& r, V3 inv, double tmi
     return tn <= tf;
 }
 
+// The float32 form of a ray for the packed bounds tests of DScene::node_pairs.  ok = false: the scene has no such frame or
+// the ray starts too far from it for float32 (a camera a long way off): the caller then uses node_box_reachable.
+struct Ray32 {
+    float ix, iy, iz, nx, ny, nz;
+    bool ok;
+};
+RT_DEV Ray32 scene_ray32(const DScene& sc, const Ray& r) {
+    Ray32 q;
+    const V3 ol = r.o - ld3(sc.pair_center);
+    const double far = fmax(fmax(fabs(ol.x), fabs(ol.y)), fabs(ol.z));
+    q.ok = sc.node_pairs != nullptr && far <= 8.0 * sc.pair_radius;  // rounding the origin then moves a plane by at most 2^-21 of the radius: the padding is 2^-16
+    q.ix = slab_inverse((float)r.d.x); q.iy = slab_inverse((float)r.d.y); q.iz = slab_inverse((float)r.d.z);
+    q.nx = -(float)ol.x * q.ix; q.ny = -(float)ol.y * q.iy; q.nz = -(float)ol.z * q.iz;
+    return q;
+}
+// Can the ray reach the bounds of nodes 2 * pair and 2 * pair + 1 within [0, tmax32]?  The pair comes through the scalar cache
+// (the index is the same for every lane), both nodes go through each packed instruction.
+RT_DEV void pair_reachable(const DScene& sc, int pair, const Ray32& q, float tmax32, bool& even, bool& odd) {
+    const RT_CONST_AS f32x2* b = (const RT_CONST_AS f32x2*)(sc.node_pairs + pair);
+    const f32x2 x0 = __builtin_elementwise_fma(b[0], f32x2{q.ix, q.ix}, f32x2{q.nx, q.nx}), x1 = __builtin_elementwise_fma(b[3], f32x2{q.ix, q.ix}, f32x2{q.nx, q.nx});
+    const f32x2 y0 = __builtin_elementwise_fma(b[1], f32x2{q.iy, q.iy}, f32x2{q.ny, q.ny}), y1 = __builtin_elementwise_fma(b[4], f32x2{q.iy, q.iy}, f32x2{q.ny, q.ny});
+    const f32x2 z0 = __builtin_elementwise_fma(b[2], f32x2{q.iz, q.iz}, f32x2{q.nz, q.nz}), z1 = __builtin_elementwise_fma(b[5], f32x2{q.iz, q.iz}, f32x2{q.nz, q.nz});
+    const f32x2 zero = {0.0f, 0.0f}, lim = {tmax32, tmax32};
+    const f32x2 tnear = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(x0, x1), __builtin_elementwise_min(y0, y1)),
+                                                  __builtin_elementwise_max(__builtin_elementwise_min(z0, z1), zero));
+    const f32x2 tfar = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(x0, x1), __builtin_elementwise_max(y0, y1)),
+                                                 __builtin_elementwise_min(__builtin_elementwise_max(z0, z1), lim));
+    even = tnear[0] <= tfar[0];
+    odd = tnear[1] <= tfar[1];
+}
+
 RT_DEV bool material_reads_uv(const DScene& sc, int material) {
     const rt_material& m = sc.materials[material];
     if (m.kind == RT_MAT_DEBUG_UV) return true;
@@ -189,9 +220,19 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
     bool hit = false;
     const bool cull = MODE == RT_MODE_FAST && !MESH_ONLY;  // a mesh clips the ray against its own root box
     V3 inv = mk(0, 0, 0);
-    if (cull) inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    Ray32 q32{};
+    q32.ok = false;
+    if (cull) {
+        q32 = scene_ray32(sc, r);
+        if (!q32.ok) inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    }
+    bool reach_even = true, reach_odd = true;
     h.leaf = -1;
     for (int i = 0; i < sc.n_nodes; i++) {
+        if (cull && q32.ok) {  // two nodes' bounds per packed test
+            if ((i & 1) == 0) pair_reachable(sc, i >> 1, q32, up32(min_dist), reach_even, reach_odd);
+            if (!((i & 1) ? reach_odd : reach_even)) continue;
+        }
         const DNode nd = sc.nodes[i];
         if (MESH_ONLY) {  // Mesh.Collide without the attributes: finish_hit() computes what the caller needs
             const DMesh& m = sc.meshes[nd.index];
@@ -212,7 +253,7 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
             }
             continue;
         }
-        if (cull && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
+        if (cull && !q32.ok && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
         Col c;
         int prim, leaf;
         const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, leaf, cnt, ls, false);
@@ -239,11 +280,22 @@ template <int MODE>
 RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self_node, LdsStack ls, VisitCounts& cnt) {
     const DNode self = sc.nodes[self_node];
     V3 inv = mk(0, 0, 0);
-    if (MODE == RT_MODE_FAST) inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    Ray32 q32{};
+    q32.ok = false;
+    if (MODE == RT_MODE_FAST) {
+        q32 = scene_ray32(sc, r);
+        if (!q32.ok) inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    }
+    const float dist32 = up32(dist);
+    bool reach_even = true, reach_odd = true;
     for (int i = 0; i < sc.n_nodes; i++) {
+        if (MODE == RT_MODE_FAST && q32.ok) {  // two nodes' bounds per packed test
+            if ((i & 1) == 0) pair_reachable(sc, i >> 1, q32, dist32, reach_even, reach_odd);
+            if (!((i & 1) ? reach_odd : reach_even)) continue;
+        }
         const DNode nd = sc.nodes[i];
         if (nd.kind == self.kind && nd.index == self.index) continue;
-        if (MODE == RT_MODE_FAST && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, kEps, dist)) continue;
+        if (MODE == RT_MODE_FAST && !q32.ok && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, kEps, dist)) continue;
         if (MODE == RT_MODE_FAST && nd.kind == RT_SHAPE_MESH) {
             double t, u, v;
             int p;
@@ -1256,10 +1308,21 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_shade(DScene sc, PassDes
 
 // ComputeDirectLighting's loop body for one (surface point, light) pair
 // (material_lambertian.go:23-52, material_metal.go:68-106, material_dielectric.go:128-170).
-template <int MODE>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_WAVES : 2) k_direct(DScene sc, Queues q, StripeCounts cnt, double* __restrict__ film) {
-    // blockIdx.y = light * stripes + stripe of the surface-point queue
-    const uint32_t stripe = blockIdx.y & (kQueueStripes - 1), light = blockIdx.y / kQueueStripes;
+// A thread takes one surface point and a run of `per_thread` lights (all lanes of a wave are on the same light at the same
+// time, so the light comes through the scalar cache): the point is fetched once for the run and what the lights add to its
+// pixel is summed before the film sees it, which with hundreds of lights is what the kernel's time went into (one set of
+// film atomics per (point, light) pair otherwise).
+// RUNS = false is the same with one light per thread and no loop around the occlusion test (the loop costs the
+// kernel 300 B of spills per lane): what scenes with a handful of lights use.
+#ifndef RT_DIRECT_RUNS_WAVES
+#define RT_DIRECT_RUNS_WAVES 2
+#endif
+template <int MODE, bool RUNS>
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (RUNS ? RT_DIRECT_RUNS_WAVES : RT_DIRECT_WAVES) : 2) k_direct(DScene sc, Queues q, StripeCounts cnt, int per_thread_arg, double* __restrict__ film) {
+    const int per_thread = RUNS ? per_thread_arg : 1;
+    // blockIdx.y = run of lights * stripes + stripe of the surface-point queue
+    const uint32_t stripe = blockIdx.y & (kQueueStripes - 1), light0 = (blockIdx.y / kQueueStripes) * (uint32_t)per_thread;
+    const uint32_t light1 = !RUNS ? light0 + 1 : (light0 + (uint32_t)per_thread < (uint32_t)sc.n_lights ? light0 + (uint32_t)per_thread : (uint32_t)sc.n_lights);
     const uint32_t at_stripe = blockIdx.x * kTraceBlock + threadIdx.x;
     const bool live = at_stripe < cnt.n[stripe];
     const uint32_t i = stripe * q.surf_stripe_cap + at_stripe;
@@ -1268,21 +1331,25 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? RT_DIRECT_
     VisitCounts vc{0, 0};
     if (live) {
         pixel = q.surfs.pixel[i];
-        const rt_light L = sc.lights[light];
         const rt_material m = sc.materials[q.surfs.material[i]];
         const V3 p = mk(q.surfs.p[0][i], q.surfs.p[1][i], q.surfs.p[2][i]);
         const V3 n = mk(q.surfs.n[0][i], q.surfs.n[1][i], q.surfs.n[2][i]);
-        V3 dir;
-        double dist;
-        const Ray sh = shadow_ray(m, L, p, n, dir, dist);
-        const bool occ = scene_occluded<MODE>(sc, sh, dist, q.surfs.node[i], LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc);
+        const int node = q.surfs.node[i];
+        uint32_t light = light0;
+        do {
+            const rt_light L = sc.lights[light];
+            V3 dir;
+            double dist;
+            const Ray sh = shadow_ray(m, L, p, n, dir, dist);
+            const bool occ = scene_occluded<MODE>(sc, sh, dist, node, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc);
+            if (!occ) {
+                V3 wo = mk(0, 0, 0), alb = mk(0, 0, 0);  // only the one the material reads is fetched
+                if (m.kind == RT_MAT_LAMBERTIAN) alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
+                else wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
+                contrib = contrib + light_contribution(m, L, n, wo, alb, q.surfs.inside[i], dir, sh.d);
+            }
+        } while (RUNS && ++light < light1);
         RT_WFLUSH(vc);
-        if (!occ) {
-            V3 wo = mk(0, 0, 0), alb = mk(0, 0, 0);  // only the one the material reads is fetched
-            if (m.kind == RT_MAT_LAMBERTIAN) alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
-            else wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
-            contrib = light_contribution(m, L, n, wo, alb, q.surfs.inside[i], dir, sh.d);
-        }
     }
     film_add_wave(film, pixel, contrib);
     report_overflow(q.counters, vc);
@@ -1519,11 +1586,18 @@ void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int i
 
 void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf, int mode, double* film, hipStream_t s) {
     if (most(n_surf) == 0 || sc.n_lights == 0) return;
-    dim3 grid(trace_blocks(most(n_surf)), (unsigned)sc.n_lights * kQueueStripes);
-    if (mode == RT_MODE_REFERENCE)
-        hipLaunchKernelGGL(k_direct<RT_MODE_REFERENCE>, grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, film);
-    else
-        hipLaunchKernelGGL(k_direct<RT_MODE_FAST>, grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, film);
+    // lights per thread: one for the usual handful; with many lights, runs of sixteen (257 lights: 17 runs)
+    int per_thread = sc.n_lights > 8 ? 16 : 1;
+    if (const char* e = getenv("RT_LIGHTS_PER_THREAD")) per_thread = std::max(1, atoi(e));
+    const unsigned runs = ((unsigned)sc.n_lights + (unsigned)per_thread - 1) / (unsigned)per_thread;
+    dim3 grid(trace_blocks(most(n_surf)), runs * kQueueStripes);
+    if (mode == RT_MODE_REFERENCE) {
+        if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_REFERENCE, true>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, film);
+        else hipLaunchKernelGGL((k_direct<RT_MODE_REFERENCE, false>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, film);
+    } else {
+        if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_FAST, true>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, film);
+        else hipLaunchKernelGGL((k_direct<RT_MODE_FAST, false>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, film);
+    }
 }
 
 #ifdef RT_VISIT_STATS

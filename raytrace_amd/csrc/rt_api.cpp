@@ -432,6 +432,67 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         std::memcpy(&node_box[i * 6], b.lo, 24);
         std::memcpy(&node_box[i * 6 + 3], b.hi, 24);
     }
+    // Packed float32 bounds, two nodes per entry (see DScene::node_pairs).  The frame is the union of the "ordinary" nodes:
+    // those whose bounds are finite and at most 64 times as large as the median node's.
+    std::vector<NodePair32> node_pairs;
+    double pair_center[3] = {0, 0, 0}, pair_radius = 0;
+    {
+        const float inf = std::numeric_limits<float>::infinity();
+        std::vector<double> sizes;
+        std::vector<char> ordinary(d->n_nodes, 0);
+        auto size_of = [&](uint64_t i) {
+            double m = 0;
+            for (int k = 0; k < 3; k++) m = std::max(m, node_box[i * 6 + 3 + k] - node_box[i * 6 + k]);
+            return m;
+        };
+        for (uint64_t i = 0; i < d->n_nodes; i++) {
+            const double sz = size_of(i);
+            if (nodes[i].kind != RT_SHAPE_MESH && std::isfinite(sz) && sz > 0) sizes.push_back(sz);
+        }
+        if (!sizes.empty()) {
+            std::nth_element(sizes.begin(), sizes.begin() + sizes.size() / 2, sizes.end());
+            const double median = sizes[sizes.size() / 2];
+            double lo[3], hi[3];
+            bool any = false;
+            for (uint64_t i = 0; i < d->n_nodes; i++) {
+                const double sz = size_of(i);
+                if (nodes[i].kind == RT_SHAPE_MESH || !std::isfinite(sz) || !(sz > 0) || sz > 64.0 * median) continue;
+                bool finite = true;
+                for (int k = 0; k < 6; k++) finite = finite && std::isfinite(node_box[i * 6 + k]);
+                if (!finite) continue;
+                ordinary[i] = 1;
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = any ? std::min(lo[k], node_box[i * 6 + k]) : node_box[i * 6 + k];
+                    hi[k] = any ? std::max(hi[k], node_box[i * 6 + 3 + k]) : node_box[i * 6 + 3 + k];
+                }
+                any = true;
+            }
+            if (any) {
+                for (int k = 0; k < 3; k++) {
+                    pair_center[k] = 0.5 * (lo[k] + hi[k]);
+                    pair_radius = std::max(pair_radius, 0.5 * (hi[k] - lo[k]));
+                }
+            }
+            if (any && pair_radius > 0 && std::isfinite(pair_radius)) {
+                const double pad = pair_radius / 65536.0;
+                node_pairs.resize((d->n_nodes + 1) / 2);
+                for (uint64_t i = 0; i < 2 * node_pairs.size(); i++) {
+                    NodePair32& np = node_pairs[i / 2];
+                    const int w = (int)(i & 1);
+                    for (int k = 0; k < 3; k++) {
+                        if (i >= d->n_nodes) { np.lo[k][w] = inf; np.hi[k][w] = -inf; continue; }  // the odd one out: never entered
+                        if (!ordinary[i]) { np.lo[k][w] = -inf; np.hi[k][w] = inf; continue; }
+                        const double a = node_box[i * 6 + k] - pair_center[k] - pad, b = node_box[i * 6 + 3 + k] - pair_center[k] + pad;
+                        float fa = (float)a, fb = (float)b;
+                        if ((double)fa > a) fa = std::nextafterf(fa, -inf);
+                        if ((double)fb < b) fb = std::nextafterf(fb, inf);
+                        np.lo[k][w] = fa;
+                        np.hi[k][w] = fb;
+                    }
+                }
+            }
+        }
+    }
     std::vector<rt_material> materials(d->materials, d->materials + d->n_materials);
     std::vector<rt_texture> textures(d->textures, d->textures + d->n_textures);
     std::vector<rt_light> lights(d->lights, d->lights + d->n_lights);
@@ -518,6 +579,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         HIP_TRY(rep->mem.upload(images, &dev.images));
         HIP_TRY(rep->mem.upload(lights, &dev.lights));
         HIP_TRY(rep->mem.upload(node_box, &dev.node_box));
+        if (!node_pairs.empty() && std::getenv("RT_NO_NODE_PAIRS") == nullptr) {
+            HIP_TRY(rep->mem.upload(node_pairs, &dev.node_pairs));
+            std::memcpy(dev.pair_center, pair_center, sizeof(pair_center));
+            dev.pair_radius = pair_radius;
+        }
         HIP_TRY(rep->mem.upload(walk_nodes, &dev.walk_nodes));
         HIP_TRY(hipEventCreateWithFlags(&rep->done, hipEventDisableTiming));
         if (r > 0) HIP_TRY(hipStreamCreateWithFlags(&rep->stream, hipStreamNonBlocking));
