@@ -414,6 +414,43 @@ def test_queues_grow_when_a_later_frame_needs_more_paths():
     assert np.abs(again.Image.astype(int) - first.Image.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("name", ["material", "charuco_leds", "zoo", "sky", "far_camera"])
+def test_packed_bounds_tests_change_nothing(name, monkeypatch):
+    """Fast mode skips a node whose bounds the ray misses; the bounds of two nodes at a time are tested in packed float32
+    (RT_NO_NODE_PAIRS=1: the float64 test per node).  Skipping is conservative, so both must give the same bytes and counters:
+    a scene with many nodes, one with 257 lights, every shape kind with transforms, one with a sky sphere that dwarfs the rest
+    (always entered) and one seen from so far away that its rays fall back to the float64 test."""
+    from test_gpu_json import zoo
+    if name == "material":
+        sc = scenes.material(dx=96, dy=96, spp=8, tex_size=(40, 36))
+    elif name == "charuco_leds":
+        sc = scenes.charuco(dx=120, dy=90, spp=2, leds=True)
+    elif name == "zoo":
+        sc = zoo()
+    else:
+        sc = scenes.cornell(dx=80, dy=72, spp=6)
+        if name == "sky":
+            sc.Node.append(scenes.PropSkySphere(1e7, phys.Emitter(phys.TextureUniform((0.2, 0.3, 0.5)))))
+        else:
+            c = sc.Camera[0]
+            back = np.asarray(c.Origin) - np.asarray(c.LowerLeftCorner) - 0.5 * np.asarray(c.Horizontal) - 0.5 * np.asarray(c.Vertical)
+            far = np.asarray(c.Origin) + 2000.0 * back  # the same view from 2000 times as far: same image plane, narrower rays
+            sc.Camera[0] = phys.PinholeCamera(c.LowerLeftCorner, tuple(far), c.Horizontal, c.Vertical)
+    out = []
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("RT_NO_NODE_PAIRS", "1")
+        else:
+            monkeypatch.delenv("RT_NO_NODE_PAIRS", raising=False)
+        with phys.DeviceScene(sc) as dev:
+            out.append([dev.render(cam, sc.RenderOptions) for cam in sc.Camera])
+    for a, b in zip(*out):
+        assert np.array_equal(a.Image, b.Image), name
+        for k in ("TotalRays", "RaysLeftScene", "RaysExceededDepth", "ShadowRays"):
+            assert getattr(a.Stats, k) == getattr(b.Stats, k), (name, k)
+    assert out[0][0].Stats.RaysLeftScene < out[0][0].Stats.TotalRays
+
+
 def test_more_lights_than_a_launch_can_address_are_refused():
     lights = [phys.PointLight((float(i), 0.0, 5.0), (1.0, 1.0, 1.0)) for i in range(2048)]
     sc = phys.Scene(Camera=[phys.OrthographicCamera((0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 2.0, 2.0)],
