@@ -1315,7 +1315,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_shade(DScene sc, PassDes
 // RUNS = false is the same with one light per thread and no loop around the occlusion test (the loop costs the
 // kernel 300 B of spills per lane): what scenes with a handful of lights use.
 #ifndef RT_DIRECT_RUNS_WAVES
-#define RT_DIRECT_RUNS_WAVES 2
+#define RT_DIRECT_RUNS_WAVES 3  // 2 waves (no spills) measured 107 ms on the 257-light frame, 3 waves (320 B of spills) 95 ms
 #endif
 template <int MODE, bool RUNS>
 __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (RUNS ? RT_DIRECT_RUNS_WAVES : RT_DIRECT_WAVES) : 2) k_direct(DScene sc, Queues q, StripeCounts cnt, int per_thread_arg, double* __restrict__ film) {
@@ -1331,7 +1331,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (RUNS ? RT
     VisitCounts vc{0, 0};
     if (live) {
         pixel = q.surfs.pixel[i];
-        const rt_material m = sc.materials[q.surfs.material[i]];
+        const rt_material& m = sc.materials[q.surfs.material[i]];  // read where it is used: a copy would sit in 18 registers across the loop
         const V3 p = mk(q.surfs.p[0][i], q.surfs.p[1][i], q.surfs.p[2][i]);
         const V3 n = mk(q.surfs.n[0][i], q.surfs.n[1][i], q.surfs.n[2][i]);
         const int node = q.surfs.node[i];
