@@ -228,6 +228,46 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
     }
     bool reach_even = true, reach_odd = true;
     h.leaf = -1;
+    // Collide of node i and the reference's update rule: keep when c.t < minDist (render.go:161)
+    auto visit = [&](int i, const DNode nd) {
+        Col c;
+        int prim, leaf;
+        const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, leaf, cnt, ls, false);
+        if (got && c.t < min_dist) {
+            min_dist = c.t;
+            h.c = c;
+            h.node = i;
+            h.prim = prim;
+            h.rec_leaf = leaf;
+            hit = true;
+        }
+    };
+    if (cull && !PACKET && sc.node_pairs != nullptr && sc.n_nodes <= 64) {
+        // Unrelated rays (scattered, or a batch): each lane first collects the nodes whose bounds ITS ray enters, then
+        // visits only those, in node order.  With the loop below a wave runs the intersection code of every node that any
+        // of its 64 rays reaches -- nearly all of them, each with a few lanes enabled.
+        if (q32.ok) {
+            unsigned long long reached = 0;
+            const float lim = up32(min_dist);
+            for (int pair = 0; 2 * pair < sc.n_nodes; pair++) {
+                bool even, odd;
+                pair_reachable(sc, pair, q32, lim, even, odd);
+                reached |= ((even ? 1ull : 0ull) | (odd ? 2ull : 0ull)) << (2 * pair);
+            }
+            if (sc.n_nodes < 64) reached &= (1ull << sc.n_nodes) - 1ull;
+            while (reached != 0) {
+                const int i = __ffsll((long long)reached) - 1;
+                reached &= reached - 1;
+                visit(i, sc.nodes[i]);
+            }
+        } else {
+            for (int i = 0; i < sc.n_nodes; i++) {
+                const DNode nd = sc.nodes[i];
+                if (nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
+                visit(i, nd);
+            }
+        }
+    } else
     for (int i = 0; i < sc.n_nodes; i++) {
         if (cull && q32.ok) {  // two nodes' bounds per packed test
             if ((i & 1) == 0) pair_reachable(sc, i >> 1, q32, up32(min_dist), reach_even, reach_odd);
@@ -254,17 +294,7 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
             continue;
         }
         if (cull && !q32.ok && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, tmin, min_dist)) continue;
-        Col c;
-        int prim, leaf;
-        const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, leaf, cnt, ls, false);
-        if (got && c.t < min_dist) {
-            min_dist = c.t;
-            h.c = c;
-            h.node = i;
-            h.prim = prim;
-            h.rec_leaf = leaf;
-            hit = true;
-        }
+        visit(i, nd);
     }
     if (!MESH_ONLY && hit) {  // the texture coordinates of the sphere that won, when something will read them
         const DNode nd = sc.nodes[h.node];
@@ -288,6 +318,27 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
     }
     const float dist32 = up32(dist);
     bool reach_even = true, reach_odd = true;
+    if (MODE == RT_MODE_FAST && sc.node_pairs != nullptr && sc.n_nodes <= 64 && sc.n_meshes == 0 && q32.ok) {
+        // as in scene_closest: each lane visits the nodes its own ray reaches (scenes without a mesh: the mesh walk below
+        // wants the lanes of a wave on the same node at the same time)
+        unsigned long long reached = 0;
+        for (int pair = 0; 2 * pair < sc.n_nodes; pair++) {
+            bool even, odd;
+            pair_reachable(sc, pair, q32, dist32, even, odd);
+            reached |= ((even ? 1ull : 0ull) | (odd ? 2ull : 0ull)) << (2 * pair);
+        }
+        if (sc.n_nodes < 64) reached &= (1ull << sc.n_nodes) - 1ull;
+        while (reached != 0) {
+            const int i = __ffsll((long long)reached) - 1;
+            reached &= reached - 1;
+            const DNode nd = sc.nodes[i];
+            if (nd.kind == self.kind && nd.index == self.index) continue;
+            Col c;
+            int prim, leaf;
+            if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, leaf, cnt, ls, false)) return true;
+        }
+        return false;
+    }
     for (int i = 0; i < sc.n_nodes; i++) {
         if (MODE == RT_MODE_FAST && q32.ok) {  // two nodes' bounds per packed test
             if ((i & 1) == 0) pair_reachable(sc, i >> 1, q32, dist32, reach_even, reach_odd);
