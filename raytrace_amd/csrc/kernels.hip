@@ -214,7 +214,8 @@ RT_DEV bool material_reads_uv(const DScene& sc, int material) {
 // node is a plain mesh, so the other shapes' code (and its registers) is left out.
 // PACKET (fast mode): the lanes of the wave trace neighbouring rays and walk each mesh together.
 // all_uv: texture coordinates also for hits whose material never reads them (validation entry point).
-template <int MODE, bool MESH_ONLY = false, bool PACKET = false>
+// NO_MESH: the host has checked that no node holds a mesh.
+template <int MODE, bool MESH_ONLY = false, bool PACKET = false, bool NO_MESH = false>
 RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tmax, SceneHit& h, VisitCounts& cnt, LdsStack ls, bool all_uv = false) {
     double min_dist = tmax;
     bool hit = false;
@@ -255,10 +256,23 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
                 reached |= ((even ? 1ull : 0ull) | (odd ? 2ull : 0ull)) << (2 * pair);
             }
             if (sc.n_nodes < 64) reached &= (1ull << sc.n_nodes) - 1ull;
-            while (reached != 0) {
-                const int i = __ffsll((long long)reached) - 1;
-                reached &= reached - 1;
-                visit(i, sc.nodes[i]);
+            // A node that holds a mesh is visited by all its lanes at the same time (the walk fetches the tree through the
+            // scalar cache while the lanes stand on the same node of the same mesh); each lane takes the nodes of its list that
+            // come before that one first, so the order per ray stays the node order.
+            unsigned long long meshes = NO_MESH ? 0ull : sc.walk_mask;
+            for (;;) {
+                const int k = meshes != 0 ? __ffsll((long long)meshes) - 1 : 64;
+                unsigned long long mine = k < 64 ? reached & ((1ull << k) - 1ull) : reached;
+                reached &= ~mine;
+                while (mine != 0) {
+                    const int i = __ffsll((long long)mine) - 1;
+                    mine &= mine - 1;
+                    visit(i, sc.nodes[i]);
+                }
+                if (NO_MESH || k == 64) break;
+                if ((reached >> k) & 1ull) visit(k, sc.nodes[k]);
+                reached &= ~(1ull << k);
+                meshes &= meshes - 1;
             }
         } else {
             for (int i = 0; i < sc.n_nodes; i++) {
@@ -612,13 +626,13 @@ RT_DEV int after_closest(const DScene& sc, const Ray& r, V3 rad, bool any, Scene
 // The first half of tracePath for one ray (render.go:143-173): NaN guard, closest hit, miss.
 // Returns -1 = invalid ray, 0 = the ray left the scene, 1 = hit an emitting-only material
 // (`emission` set), 2 = hit needs Material.Resolve (`h` set).
-template <int MODE, bool MESH_ONLY, bool PACKET = false>
+template <int MODE, bool MESH_ONLY, bool PACKET = false, bool NO_MESH = false>
 RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& emission, LdsStack ls, VisitCounts& cnt) {
     if (bad3(r.o) || bad3(r.d)) return -1;  // render.go:147-150
 #ifdef RT_VISIT_STATS
     const long long closest_t0 = clock64();
 #endif
-    const bool any = scene_closest<MODE, MESH_ONLY, PACKET>(sc, r, kEps, kMaxFloat, h, cnt, ls);
+    const bool any = scene_closest<MODE, MESH_ONLY, PACKET, NO_MESH>(sc, r, kEps, kMaxFloat, h, cnt, ls);
 #ifdef RT_VISIT_STATS
     RT_STAT(12, clock64() - closest_t0);
 #endif
@@ -962,7 +976,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDes
         ps.path = rays.path[i];
         ps.depth_n = rays.depth_n[i];
         V3 em;
-        const int what = trace_one<MODE, false>(sc, r, ps.rad, h, em, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc);
+        const int what = trace_one<MODE, false, false, true>(sc, r, ps.rad, h, em, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc);
         if (what == 0) n_left = 1;
         if (what == 1) add = em;
         want = what == 2;

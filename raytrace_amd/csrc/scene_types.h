@@ -118,6 +118,7 @@ struct DScene {
     // other node when it fetches a ray and then walks these trees one after the other, resumably.
     int32_t n_walk_nodes;
     const int32_t* walk_nodes;
+    uint64_t walk_mask;  // the same as bits, for scenes of at most 64 nodes (bit i: node i holds a mesh)
 };
 
 struct DCamera {

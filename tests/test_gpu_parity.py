@@ -113,6 +113,49 @@ def test_fast_mode_hits_match_reference_t_exact(ob, case):
     assert np.array_equal(g["uv"][hit][same], c["uv"][hit][same])
 
 
+def test_fast_mode_unrelated_rays_in_a_scene_of_meshes_among_other_shapes(ob):
+    """A batch of unrelated rays in fast mode: every lane lists the nodes its own ray reaches, and the nodes that hold a mesh
+    (plain or under a transform) are still entered by all their lanes together.  Three meshes between spheres, quads and a
+    cylinder; the oracle decides node, distance and attributes."""
+    rng = np.random.default_rng(21)
+    v, t = scenes.icosphere(3)
+    uv = np.abs(v[:, :2])
+
+    def ball(center, radius):
+        return phys.NewMesh(scenes.faces_from(v * radius + np.asarray(center), uv, t))
+
+    turn = phys.Transform((0.0, -2.5, 0.3), phys.RotationMatrixZ(0.9), (1.0, 0.6, 1.2))
+    mat = phys.DebugNormal()
+    nodes = [phys.Node("q0", phys.Quad((0.0, 0.0, -1.5), (0.0, 0.0, 1.0), 14.0, 14.0), mat),
+             phys.Node("m0", ball((2.5, 0.0, 0.0), 0.9), mat),
+             phys.Node("s0", phys.Sphere((0.0, 0.0, 0.0), 0.7), mat),
+             phys.Node("s1", phys.Sphere((-2.5, 2.0, 0.5), 0.6), mat),
+             phys.Node("m1", phys.TransformedShape(ball((0.0, 0.0, 0.0), 0.8), turn), mat),
+             phys.Node("c0", phys.Cylinder((-2.5, -2.0, -1.0), (0.0, 0.0, 1.0), 0.5, 1.5), mat),
+             phys.Node("m2", ball((0.0, 2.8, 0.4), 0.7), mat),
+             phys.Node("q1", phys.Quad((3.5, 3.5, 0.0), (-1.0, -1.0, 0.3), 2.0, 2.0), mat)]
+    sc = phys.Scene(Camera=[], Node=nodes)
+    n = 60000
+    o = rng.normal(size=(n, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(4.0, 9.0, size=(n, 1))
+    d = rng.uniform(-3.5, 3.5, size=(n, 3)) * np.array([1.0, 1.0, 0.4]) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    with phys.DeviceScene(sc) as dev, ob.OracleScene(sc) as orc:
+        g = dev.intersect(o, d, 1e-6, MAXF, abi.MODE_FAST)
+        c = orc.intersect(o, d, 1e-6, MAXF)
+    assert np.array_equal(g["node"], c["node"])
+    for k in range(len(nodes)):
+        assert (c["node"] == k).sum() > 50, nodes[k].Name
+    hit = c["node"] >= 0
+    assert np.array_equal(g["t"][hit], c["t"][hit])
+    same = g["prim"][hit] == c["prim"][hit]
+    assert same.mean() > 0.999, same.mean()
+    assert np.array_equal(g["normal"][hit][same], c["normal"][hit][same])
+    round_shape = np.isin(c["node"][hit][same], [2, 3, 5])  # sphere / cylinder coordinates go through atan2 and acos: the last bit is libm's
+    assert np.array_equal(g["uv"][hit][same][~round_shape], c["uv"][hit][same][~round_shape])
+    assert np.allclose(g["uv"][hit][same][round_shape], c["uv"][hit][same][round_shape], rtol=0, atol=1e-12)
+
+
 def test_fast_mode_drops_never_hit_flat_subtrees(ob):
     # AABB.hit rejects tmax <= tmin (shape.go:91): a leaf whose faces are coplanar with an axis
     # plane has a zero-thickness box and is never entered by the reference.  Fast mode must agree.
