@@ -364,8 +364,10 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
         if (MODE == RT_MODE_FAST && nd.kind == RT_SHAPE_MESH) {
             double t, u, v;
             int p;
-            // (a four-wide any-hit walk was tried here and lost: neighbouring surface points send their shadow rays the same way,
-            // and this walk fetches a node the whole wave stands on once, through the scalar cache)
+            // (Two other walks were tried here and lost.  The four-wide one of k_walk: a third slower, also on the points of
+            // scattered rays alone.  The wave-packet one of the camera rays, for the points a primary pass queued, whose shadow
+            // rays to one light run side by side: also a third slower; this walk already fetches a node the whole wave stands
+            // on once, through the scalar cache.)
             if (mesh_collide_fast<true>(sc, sc.meshes[nd.index], r, kEps, dist, p, t, u, v, ls.lds, ls.stride, ls.cap, cnt)) return true;
             continue;
         }
@@ -1383,12 +1385,18 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_shade(DScene sc, PassDes
 #define RT_DIRECT_RUNS_WAVES 3  // 2 waves (no spills) measured 107 ms on the 257-light frame, 3 waves (320 B of spills) 95 ms
 #endif
 template <int MODE, bool RUNS>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (RUNS ? RT_DIRECT_RUNS_WAVES : RT_DIRECT_WAVES) : 2) k_direct(DScene sc, Queues q, StripeCounts cnt, int per_thread_arg, double* __restrict__ film) {
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (RUNS ? RT_DIRECT_RUNS_WAVES : RT_DIRECT_WAVES) : 2) k_direct(DScene sc, Queues q, StripeCounts cnt, int per_thread_arg, uint32_t n_runs, uint32_t group, double* __restrict__ film) {
     const int per_thread = RUNS ? per_thread_arg : 1;
-    // blockIdx.y = run of lights * stripes + stripe of the surface-point queue
-    const uint32_t stripe = blockIdx.y & (kQueueStripes - 1), light0 = (blockIdx.y / kQueueStripes) * (uint32_t)per_thread;
+    // blockIdx.y = stripe of the surface-point queue.  blockIdx.x = `group` chunks of 64 points for the first run of lights, the
+    // same chunks for the second run, ..., then the next group of chunks.  group = 8 (many lights): workgroups are dealt
+    // round-robin to the 8 XCDs, so the runs of a chunk execute on one XCD one right after the other and all but the first
+    // find the points in its L2 instead of in device memory.  group = every chunk of the stripe (a handful of lights): a run
+    // is finished before the next begins; side by side the runs' film atomics on the same pixels get in each other's way,
+    // which costs more than the second read of the points.
+    const uint32_t stripe = blockIdx.y, run = (blockIdx.x / group) % n_runs, chunk = (blockIdx.x / (group * n_runs)) * group + blockIdx.x % group;
+    const uint32_t light0 = run * (uint32_t)per_thread;
     const uint32_t light1 = !RUNS ? light0 + 1 : (light0 + (uint32_t)per_thread < (uint32_t)sc.n_lights ? light0 + (uint32_t)per_thread : (uint32_t)sc.n_lights);
-    const uint32_t at_stripe = blockIdx.x * kTraceBlock + threadIdx.x;
+    const uint32_t at_stripe = chunk * kTraceBlock + threadIdx.x;
     const bool live = at_stripe < cnt.n[stripe];
     const uint32_t i = stripe * q.surf_stripe_cap + at_stripe;
     uint32_t pixel = 0xffffffffu;
@@ -1406,13 +1414,15 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (RUNS ? RT
             V3 dir;
             double dist;
             const Ray sh = shadow_ray(m, L, p, n, dir, dist);
-            const bool occ = scene_occluded<MODE>(sc, sh, dist, node, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc);
-            if (!occ) {
-                V3 wo = mk(0, 0, 0), alb = mk(0, 0, 0);  // only the one the material reads is fetched
-                if (m.kind == RT_MAT_LAMBERTIAN) alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
-                else wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
-                contrib = contrib + light_contribution(m, L, n, wo, alb, q.surfs.inside[i], dir, sh.d);
-            }
+            // What the light adds if nothing is in the way comes first: when that is exactly zero (a light behind the surface:
+            // half of all pairs on a closed mesh) the sum is the same with or without it, and the occlusion test, which for such
+            // a ray is a walk that starts inside the mesh, is not run at all.  (A NaN is not zero: it is still tested and added.)
+            V3 wo = mk(0, 0, 0), alb = mk(0, 0, 0);  // only the one the material reads is fetched
+            if (m.kind == RT_MAT_LAMBERTIAN) alb = mk(q.surfs.albedo[0][i], q.surfs.albedo[1][i], q.surfs.albedo[2][i]);
+            else wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
+            const V3 adds = light_contribution(m, L, n, wo, alb, q.surfs.inside[i], dir, sh.d);
+            if (MODE == RT_MODE_FAST && adds.x == 0 && adds.y == 0 && adds.z == 0) continue;
+            if (!scene_occluded<MODE>(sc, sh, dist, node, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc)) contrib = contrib + adds;
         } while (RUNS && ++light < light1);
         RT_WFLUSH(vc);
     }
@@ -1655,13 +1665,14 @@ void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf
     int per_thread = sc.n_lights > 8 ? 16 : 1;
     if (const char* e = getenv("RT_LIGHTS_PER_THREAD")) per_thread = std::max(1, atoi(e));
     const unsigned runs = ((unsigned)sc.n_lights + (unsigned)per_thread - 1) / (unsigned)per_thread;
-    dim3 grid(trace_blocks(most(n_surf)), runs * kQueueStripes);
+    const unsigned chunks = (trace_blocks(most(n_surf)) + 7u) / 8u * 8u, group = runs > 2 ? 8u : chunks;
+    dim3 grid(chunks * runs, kQueueStripes);
     if (mode == RT_MODE_REFERENCE) {
-        if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_REFERENCE, true>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, film);
-        else hipLaunchKernelGGL((k_direct<RT_MODE_REFERENCE, false>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, film);
+        if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_REFERENCE, true>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, runs, group, film);
+        else hipLaunchKernelGGL((k_direct<RT_MODE_REFERENCE, false>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, runs, group, film);
     } else {
-        if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_FAST, true>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, film);
-        else hipLaunchKernelGGL((k_direct<RT_MODE_FAST, false>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, film);
+        if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_FAST, true>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, runs, group, film);
+        else hipLaunchKernelGGL((k_direct<RT_MODE_FAST, false>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, runs, group, film);
     }
 }
 

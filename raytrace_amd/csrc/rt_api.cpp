@@ -475,6 +475,18 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             }
             if (any && pair_radius > 0 && std::isfinite(pair_radius)) {
                 const double pad = pair_radius / 65536.0;
+                // A mesh that lies within 16 radii of the frame gets its real bounds too (float32 rounding of the slab
+                // products then moves a plane by at most 2^-20 of the radius): a ray that misses them is spared the mesh's
+                // own float64 clip, which is what most shadow rays and most camera rays of a small mesh on a large floor pay.
+                for (uint64_t i = 0; i < d->n_nodes; i++) {
+                    if (nodes[i].kind != RT_SHAPE_MESH) continue;
+                    bool near = true;
+                    for (int k = 0; k < 3; k++)
+                        near = near && std::isfinite(node_box[i * 6 + k]) && std::isfinite(node_box[i * 6 + 3 + k]) &&
+                               std::fabs(node_box[i * 6 + k] - pair_center[k]) <= 16.0 * pair_radius &&
+                               std::fabs(node_box[i * 6 + 3 + k] - pair_center[k]) <= 16.0 * pair_radius;
+                    if (near) ordinary[i] = 1;
+                }
                 node_pairs.resize((d->n_nodes + 1) / 2);
                 for (uint64_t i = 0; i < 2 * node_pairs.size(); i++) {
                     NodePair32& np = node_pairs[i / 2];
