@@ -520,6 +520,13 @@ struct PathState {
 // appended to the next generation (ballot compaction, one atomic per wave and queue), the surface point appended
 // for ComputeDirectLighting.  Returns the hit's emission, which the caller adds to the film.  Must be reached by
 // all lanes of the wave.
+// EARLY (fast mode): a child whose ray enters no node's bounds has left the scene the moment it is made: it is counted as
+// traced and as having left (render.go:170-173: a miss adds nothing) and never queued -- in an open scene that is most of
+// the children.  The bounds are the packed ones of scene_closest; the node the ray starts on (whose bounds hold the
+// origin) is tested exactly instead when it is a plain shape, so the outcome is the one the node loop would reach.
+// (Not compiled into the kernels of mesh-only scenes, which have no such bounds: there it only costs registers.)
+RT_DEV bool simple_collide(const DScene& sc, int kind, int index, const Ray& r, double tmin, double tmax, Col& c);
+template <bool EARLY>
 RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, int out, uint32_t stripe, bool live, const Ray& r,
                        const PathState& ps, const SceneHit& h) {
     const RayQ& next = q.rays[out];
@@ -556,18 +563,43 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
             inside = lit.inside;
         }
     }
-    wave_tally(q.counters, n_counted, 0, n_cut);
     // class of a child: 1 when it can reach a mesh (scenes that mix meshes with other shapes, see DScene::walk_box)
     int cls[2] = {0, 0};
-    if (sc.walk_classes) {
+    uint32_t n_gone = 0;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            if (!child_ok[k]) continue;
-            const Ray cr{at, sct.dir[k]};
+    for (int k = 0; k < 2; k++) {
+        if (!child_ok[k]) continue;
+        const Ray cr{at, sct.dir[k]};
+        bool may_walk = true;
+        if (EARLY && sc.early_miss && sc.node_pairs != nullptr && sc.n_nodes <= 64) {
+            const Ray32 q32 = scene_ray32(sc, cr);
+            if (q32.ok) {
+                unsigned long long reached = 0;
+                for (int pair = 0; 2 * pair < sc.n_nodes; pair++) {
+                    bool even, odd;
+                    pair_reachable(sc, pair, q32, __builtin_inff(), even, odd);
+                    reached |= ((even ? 1ull : 0ull) | (odd ? 2ull : 0ull)) << (2 * pair);
+                }
+                if (sc.n_nodes < 64) reached &= (1ull << sc.n_nodes) - 1ull;
+                const DNode self = sc.nodes[h.node];
+                if (((reached >> h.node) & 1ull) && self.kind != RT_SHAPE_MESH && self.kind != RT_SHAPE_TRANSFORMED) {
+                    Col c;
+                    if (!simple_collide(sc, self.kind, self.index, cr, kEps, kMaxFloat, c)) reached &= ~(1ull << h.node);
+                }
+                if (reached == 0) {
+                    child_ok[k] = false;
+                    n_gone++;
+                    continue;
+                }
+                may_walk = (reached & sc.walk_mask) != 0;
+            }
+        }
+        if (sc.walk_classes && may_walk) {
             const V3 inv = mk(1.0 / cr.d.x, 1.0 / cr.d.y, 1.0 / cr.d.z);
             cls[k] = node_box_reachable(sc.walk_box, cr, inv, kEps, kMaxFloat) ? 1 : 0;
         }
     }
+    wave_tally(q.counters, n_counted + n_gone, n_gone, n_cut);
     for (int c = 0; c <= sc.walk_classes; c++) {
         // both children of every lane in one reservation per class: first children first, in lane order, then the second ones
         const unsigned long long m0 = __ballot(child_ok[0] && cls[0] == c), m1 = __ballot(child_ok[1] && cls[1] == c);
@@ -847,7 +879,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
             n_left += (uint32_t)__popcll(__ballot(missed));
             if (SHADE) {
                 // successive rounds of a wave append to successive stripes: over a launch every stripe receives its share
-                const V3 em2 = shade_lane(sc, pass, q, 1, rot++ & (kQueueStripes - 1), want, r, ps, h);
+                const V3 em2 = shade_lane<MODE == RT_MODE_FAST && !MESH_ONLY>(sc, pass, q, 1, rot++ & (kQueueStripes - 1), want, r, ps, h);
                 if (want) { acc_lds[0] += em2.x; acc_lds[64] += em2.y; acc_lds[128] += em2.z; }
             }
 #ifdef RT_VISIT_STATS
@@ -983,7 +1015,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_trace(DScene sc, PassDes
         if (what == 1) add = em;
         want = what == 2;
     }
-    const V3 em2 = shade_lane(sc, pass, q, 1 - in, (blockIdx.x + blockIdx.y) & (kQueueStripes - 1), want, r, ps, h);
+    const V3 em2 = shade_lane<MODE == RT_MODE_FAST>(sc, pass, q, 1 - in, (blockIdx.x + blockIdx.y) & (kQueueStripes - 1), want, r, ps, h);
     if (want) add = em2;
     film_add_wave(film, ps.pixel, add);
     wave_tally(q.counters, 0, n_left, 0);  // the rays of this launch themselves are counted by the host
@@ -1367,7 +1399,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_shade(DScene sc, PassDes
                 else want = true;
             }
         }
-        const V3 em2 = shade_lane(sc, pass, q, 1 - in, (stripe + k) & (kQueueStripes - 1), want, r, ps, h);
+        const V3 em2 = shade_lane<MODE == RT_MODE_FAST && !MESH_ONLY>(sc, pass, q, 1 - in, (stripe + k) & (kQueueStripes - 1), want, r, ps, h);
         if (want) add = em2;
         film_add_wave(film, ps.pixel, add);
     }

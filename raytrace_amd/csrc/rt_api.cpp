@@ -536,6 +536,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (const char* e = std::getenv("RT_STACK_PAIRS")) stack_pairs = walk_cap = std::max(1, std::atoi(e));
     DScene proto{};
     proto.n_walk_nodes = (int32_t)walk_nodes.size();
+    proto.early_miss = std::getenv("RT_NO_EARLY_MISS") == nullptr ? 1 : 0;
     if (d->n_nodes <= 64)
         for (int32_t i : walk_nodes) proto.walk_mask |= 1ull << i;
     proto.n_nodes = (int32_t)d->n_nodes;

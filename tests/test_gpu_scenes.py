@@ -451,6 +451,35 @@ def test_packed_bounds_tests_change_nothing(name, monkeypatch):
     assert out[0][0].Stats.RaysLeftScene < out[0][0].Stats.TotalRays
 
 
+@pytest.mark.parametrize("name", ["material", "teapot", "zoo", "charuco_leds"])
+def test_rays_settled_where_they_are_made_change_nothing(name, monkeypatch):
+    """Fast mode counts a scattered ray that enters no node's bounds as traced and gone when it is made, instead of queueing
+    it for the next launch (RT_NO_EARLY_MISS=1: every child is queued).  Same bytes, same counters -- in open scenes, where
+    most children go that way, with a mesh among the nodes and without."""
+    from test_gpu_json import zoo
+    if name == "material":
+        sc = scenes.material(dx=96, dy=96, spp=8, tex_size=(40, 36))
+    elif name == "teapot":
+        sc = scenes.teapot(dx=128, dy=72, spp=8)
+    elif name == "zoo":
+        sc = zoo()
+    else:
+        sc = scenes.charuco(dx=120, dy=90, spp=2, leds=True)
+    out = []
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("RT_NO_EARLY_MISS", "1")
+        else:
+            monkeypatch.delenv("RT_NO_EARLY_MISS", raising=False)
+        with phys.DeviceScene(sc) as dev:
+            out.append([dev.render(cam, sc.RenderOptions) for cam in sc.Camera])
+    for a, b in zip(*out):
+        assert np.array_equal(a.Image, b.Image), name
+        for k in ("TotalRays", "RaysLeftScene", "RaysExceededDepth", "ShadowRays"):
+            assert getattr(a.Stats, k) == getattr(b.Stats, k), (name, k)
+    assert 0 < out[0][0].Stats.RaysLeftScene < out[0][0].Stats.TotalRays
+
+
 def test_more_lights_than_a_launch_can_address_are_refused():
     lights = [phys.PointLight((float(i), 0.0, 5.0), (1.0, 1.0, 1.0)) for i in range(2048)]
     sc = phys.Scene(Camera=[phys.OrthographicCamera((0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 2.0, 2.0)],
