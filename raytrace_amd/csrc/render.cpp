@@ -121,12 +121,22 @@ hipError_t copy_rays(const RayQ& dst, uint64_t dst_at, const RayQ& src, uint64_t
 }
 
 // want_paths: the camera paths of the render about to run (pixels of this device's share x samples of the call).  The
-// queues of a scattering scene cost 650 bytes per path of a launch (21 GB at the default of 2^25 paths), so they are
-// sized for the frame at hand, between 2^18 and 2^25 paths, and grow when a later frame needs more: a host that keeps
-// many small scenes alive does not pay for a 4K frame in each.  RT_QUEUE_RAYS fixes the size instead.
+// queues of a scattering scene cost 650 bytes per path of a launch (21 GB at 2^25 paths; 1000 bytes with two classes of
+// rays), so they are sized for the frame at hand, between 2^18 and 2^25 paths, and grow when a later frame needs more: a
+// host that keeps many small scenes alive does not pay for a 4K frame in each.  A frame of more paths than that is
+// traced in passes, each with its tail of small launches for the late generations; one more doubling (a 1080p frame at
+// 32 samples in one pass instead of two: 8 % faster) is taken only when it leaves more than half of the device's memory
+// free.  RT_QUEUE_RAYS fixes the size instead.
 int ensure_work(const rt_scene* sc, Replica& rep, uint64_t want_paths) {
-    size_t q_want = (size_t)1 << 18;
-    while (q_want < ((size_t)1 << 25) && q_want < want_paths) q_want <<= 1;
+    size_t q_want = (size_t)1 << 18, q_top = (size_t)1 << 25;
+    if (rep.work && rep.work->q > q_top) {
+        q_top = rep.work->q;  // taken before
+    } else if (want_paths > q_top && !sc->all_terminal) {
+        size_t free_b = 0, total_b = 0;
+        const size_t cost = 2 * q_top * (rep.dev.walk_classes ? 1000 : 650);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > cost && free_b - cost > total_b / 2) q_top *= 2;
+    }
+    while (q_want < q_top && q_want < want_paths) q_want <<= 1;
     if (std::getenv("RT_QUEUE_RAYS")) q_want = env_size("RT_QUEUE_RAYS", (size_t)1 << 25);
     if (q_want < 64 * 64) q_want = 64 * 64;
     if (rep.work && (sc->all_terminal || rep.work->q >= q_want)) return RT_OK;  // a scene that never shades never queues
