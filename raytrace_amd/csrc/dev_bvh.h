@@ -400,6 +400,9 @@ struct WalkLane {
 #ifndef RT_WALK_RING
 #define RT_WALK_RING 8
 #endif
+#ifndef RT_WALK_BREAK
+#define RT_WALK_BREAK 0
+#endif
 constexpr int kWalkRing = RT_WALK_RING;
 static_assert((kWalkRing & (kWalkRing - 1)) == 0, "the ring index is a mask");
 struct WalkStack {
@@ -579,6 +582,9 @@ RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin
             overflow = true;  // the host sizes the stack from the deepest tree: cannot happen, but must not pass silently
         }
     };
+#if RT_WALK_BREAK
+    const int entry_n = __popcll(__builtin_amdgcn_ballot_w64(true));
+#endif
     while (w.cur >= 0) {
 #ifdef RT_VISIT_STATS
         w.steps++;
@@ -615,8 +621,12 @@ RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin
         } else {
             pop_next();
         }
+#if RT_WALK_BREAK
+        // the few lanes still among inner nodes stop here and go on in the next round: the others' leaves are not kept waiting
+        if (__popcll(__builtin_amdgcn_ballot_w64(w.cur >= 0)) * 100 < entry_n * RT_WALK_BREAK) break;
+#endif
     }
-    if (w.cur == kFastEmpty) return;
+    if (w.cur == kFastEmpty || w.cur >= 0) return;
     const uint32_t code = (uint32_t)~w.cur;
     const int32_t first = (int32_t)(code >> 3);
     const int32_t count = (int32_t)(code & 7u) + 1;

@@ -477,6 +477,7 @@ RT_DEV void film_add(double* film, uint32_t pixel, V3 v) {
 // per-XCD L2s, where thousands of waves queue: a run of 16 samples costs 3 of them instead of 48.  Must be reached
 // by all lanes of the wave; a lane with nothing to add passes v = 0 (any pixel).
 RT_DEV void film_add_wave(double* film, uint32_t pixel, V3 v) {
+    if (__ballot(v.x != 0 || v.y != 0 || v.z != 0) == 0) return;  // nothing to add in the whole wave (a NaN is not zero)
     const int lane = threadIdx.x & 63;
     const uint32_t prev = __shfl_up(pixel, 1, 64);
     const bool head = lane == 0 || prev != pixel;
@@ -545,7 +546,11 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
         at = c.at;
         const uint32_t x = ps.pixel % (uint32_t)pass.dx, row = ps.pixel / (uint32_t)pass.dx;
         Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(pass.dy - 1 - (int)row) * (uint32_t)pass.dx + x, ps.sample, ps.path, ps.depth_n & 0xFFFFFFu};
+#ifdef RT_KO_RESOLVE
+        sct.n = 0; sct.emission = mk(0, 0, 0); sct.albedo = mk(0, 0, 0);
+#else
         resolve(sc, m, r.d, ps.rad, c, rng, sct);
+#endif
         emission = sct.emission;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -1322,86 +1327,137 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_walk(DScene sc, Queues q
     report_overflow(C, vc);
 }
 
-// The second half of tracePath (render.go:174-183) for the hits k_walk recorded: attributes of the hit, Material.Resolve,
-// children appended to the next generation, the surface point queued for the light loop, emission added to the film.
-// Persistent waves deal the chunks of 64 records among themselves round-robin (the work per record is even).
-template <int MODE, bool MESH_ONLY, int WAVES>
-__global__ void __launch_bounds__(kTraceBlock, WAVES) k_shade(DScene sc, PassDesc pass, Queues q, int in, double* __restrict__ film) {
+// Threads of the workgroups that put their items in the order of their materials before Material.Resolve (four waves).
+constexpr int kSortBlock = 256;
+
+// Sort key of a hit: the code Material.Resolve runs for it.  0 Lambertian, 1 Metal, 2 Dielectric, 3 the materials that only emit.
+RT_DEV int material_key(const DScene& sc, int32_t node) {
+    const int kind = sc.materials[sc.nodes[node].material].kind;
+    return kind == RT_MAT_LAMBERTIAN ? 0 : (kind == RT_MAT_METAL ? 1 : (kind == RT_MAT_DIELECTRIC ? 2 : 3));
+}
+
+// Puts the items of a kSortBlock-thread workgroup in the order of their keys (0..3; 4 = this thread has no item), keeping the
+// order inside a key: thread j gets back the thread whose item is j-th (-1 when there are fewer items) and the number of
+// items.  Materials differ in what Resolve costs by an order of magnitude and share no code; hits arrive in whatever order
+// their rays ended, so a wave that takes them as they come runs every material's code with a fraction of its lanes.  After
+// this the waves of the workgroup hold one material each (at most three of the four see a boundary).  Must be reached by
+// every thread of the workgroup; two barriers.
+RT_DEV int block_order(int key, int& total) {
+    __shared__ int s_count[4 * 4];
+    __shared__ int s_src[kSortBlock];
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const unsigned long long m0 = __ballot(key == 0), m1 = __ballot(key == 1), m2 = __ballot(key == 2), m3 = __ballot(key == 3);
+    if (lane < 4) s_count[wave * 4 + lane] = __popcll(lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3)));
+    __syncthreads();
+    int base = 0, n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int c = s_count[w * 4 + k];
+            if (k < key || (k == key && w < wave)) base += c;
+            n += c;
+        }
+    if (key < 4) {
+        const unsigned long long mine = key == 0 ? m0 : (key == 1 ? m1 : (key == 2 ? m2 : m3));
+        s_src[base + __popcll(mine & ((1ull << lane) - 1ull))] = (int)threadIdx.x;
+    }
+    __syncthreads();
+    total = n;
+    return (int)threadIdx.x < n ? s_src[threadIdx.x] : -1;
+}
+
+// The second half of tracePath (render.go:174-183) for one recorded hit per lane: the ray comes back from its queue slot,
+// the attributes of the hit are computed again from (node, face, distance), then Material.Resolve, the children appended to
+// the next generation, the surface point queued for the light loop, emission added to the film.  Must be reached by all
+// lanes of the wave (`live`: this lane has a record).
+template <int MODE, bool MESH_ONLY>
+RT_DEV void shade_record(const DScene& sc, const PassDesc& pass, const Queues& q, int in, uint32_t out_stripe, bool live, uint32_t slot, int32_t node,
+                         int32_t leaf, double t, double* __restrict__ film) {
     const RayQ& rays = q.rays[in];
+    bool want = false;
+    Ray r;
+    SceneHit h;
+    PathState ps;
+    ps.pixel = 0xffffffffu;
+    V3 add = mk(0, 0, 0);
+    if (live) {
+        r.o = mk(rays.o[0][slot], rays.o[1][slot], rays.o[2][slot]);
+        r.d = mk(rays.d[0][slot], rays.d[1][slot], rays.d[2][slot]);
+        ps.rad = mk(rays.rad[0][slot], rays.rad[1][slot], rays.rad[2][slot]);
+        ps.pixel = rays.pixel[slot];
+        ps.sample = rays.sample[slot];
+        ps.path = rays.path[slot];
+        ps.depth_n = rays.depth_n[slot];
+        h.node = node;
+        h.leaf = -1;
+        h.prim = 0;
+        const DNode nd = sc.nodes[h.node];
+        const rt_material& m = sc.materials[nd.material];
+        const bool terminal = terminal_kind(m.kind);
+        Ray lr = r;
+        Chain ch;
+        if (MESH_ONLY) { ch.n = 0; ch.kind = RT_SHAPE_MESH; ch.index = nd.index; }
+        else chain_down(sc, nd.kind, nd.index, lr, ch);
+        bool ok = true;
+        if (ch.kind == RT_SHAPE_MESH) {
+            // Face.Collide on the recorded face, limited to the recorded distance: the same t again, and the barycentrics
+            const DMesh& mesh = sc.meshes[ch.index];
+            const double* pos = sc.prim_pos + (mesh.prim_off + leaf) * 9;
+            const V3 p0 = ld3(pos), p1 = ld3(pos + 3), p2 = ld3(pos + 6);
+            double t2, u, v;
+            ok = mt_core(lr, p0, p1, p2, 1e-8, kEps, t, t2, u, v);
+            h.prim = sc.prim_face[mesh.prim_off + leaf];
+            face_finish(lr, p0, p1, p2, sc.face_uv + (mesh.face_off + h.prim) * 6, t, u, v, h.c);
+        } else {
+            // Any other shape: only the distance was kept.  The shape's Collide limited to that distance returns
+            // the same hit again (each returns its nearest root inside [tmin, tmax]).
+            ok = simple_collide(sc, ch.kind, ch.index, lr, kEps, t, h.c);
+            if (ok && ch.kind == RT_SHAPE_SPHERE && (ch.n > 0 || material_reads_uv(sc, nd.material))) sphere_uv(sc.spheres[ch.index], h.c);
+        }
+        if (!ok) {
+            atomicAdd(&q.counters->errors.v, 1u);
+        } else {
+            if (ch.n > 0) chain_up(sc, ch, h.c);
+            if (terminal) add = terminal_emission(sc, m, h.c, ps.rad);
+            else want = true;
+        }
+    }
+    const V3 em2 = shade_lane<MODE == RT_MODE_FAST && !MESH_ONLY>(sc, pass, q, 1 - in, out_stripe, want, r, ps, h);
+    if (want) add = em2;
+    film_add_wave(film, ps.pixel, add);
+}
+
+// shade_record for the hits k_walk recorded.  Persistent workgroups of four waves deal the chunks of kSortBlock records among
+// themselves round-robin (the work per record is even) and take the records of a chunk in the order of their materials.
+template <int MODE, bool MESH_ONLY, int WAVES>
+__global__ void __launch_bounds__(kSortBlock, WAVES) k_shade(DScene sc, PassDesc pass, Queues q, int in, double* __restrict__ film) {
     const HitQ& hq = q.hits;
-    Counters* const C = q.counters;
-    const Counters::Cursor* const counts = C->hit_cursor;
-    const uint32_t lane = threadIdx.x;
+    const Counters::Cursor* const counts = q.counters->hit_cursor;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
     uint32_t most = 0;
     for (int s = 0; s < kQueueStripes; s++) {
         const uint32_t n = counts[s].v;
         most = most > n ? most : n;
     }
     most = most < q.hit_stripe_cap ? most : q.hit_stripe_cap;
-    const uint32_t chunks = (most + 63u) / 64u * (uint32_t)kQueueStripes;  // chunk c: records [64 (c / stripes), +64) of stripe c % stripes
+    // chunk c: records [kSortBlock (c / stripes), + kSortBlock) of stripe c % stripes; its wave w appends to stripe
+    // (stripe + 4 (c / stripes) + w) % stripes, so a stripe takes the children of at most most / 64 waves
+    const uint32_t chunks = (most + (uint32_t)kSortBlock - 1u) / (uint32_t)kSortBlock * (uint32_t)kQueueStripes;
     for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
         const uint32_t stripe = c & (kQueueStripes - 1), k = c / kQueueStripes;
         uint32_t n_s = counts[stripe].v;
         n_s = n_s < q.hit_stripe_cap ? n_s : q.hit_stripe_cap;
-        const uint32_t i = k * 64u + lane;
-        const size_t at = (size_t)stripe * q.hit_stripe_cap + i;
-        uint32_t slot = kNoRay;
-        if (i < n_s) slot = hq.ray[at];
-        const bool live = slot != kNoRay;
-        if (__ballot(live) == 0) continue;
-        bool want = false;
-        Ray r;
-        SceneHit h;
-        PathState ps;
-        ps.pixel = 0xffffffffu;
-        V3 add = mk(0, 0, 0);
-        if (live) {
-            r.o = mk(rays.o[0][slot], rays.o[1][slot], rays.o[2][slot]);
-            r.d = mk(rays.d[0][slot], rays.d[1][slot], rays.d[2][slot]);
-            ps.rad = mk(rays.rad[0][slot], rays.rad[1][slot], rays.rad[2][slot]);
-            ps.pixel = rays.pixel[slot];
-            ps.sample = rays.sample[slot];
-            ps.path = rays.path[slot];
-            ps.depth_n = rays.depth_n[slot];
-            h.node = hq.node[at];
-            h.leaf = -1;
-            h.prim = 0;
-            const int32_t leaf = hq.leaf[at];
-            const double t = hq.t[at];
-            const DNode nd = sc.nodes[h.node];
-            const rt_material& m = sc.materials[nd.material];
-            const bool terminal = terminal_kind(m.kind);
-            Ray lr = r;
-            Chain ch;
-            if (MESH_ONLY) { ch.n = 0; ch.kind = RT_SHAPE_MESH; ch.index = nd.index; }
-            else chain_down(sc, nd.kind, nd.index, lr, ch);
-            bool ok = true;
-            if (ch.kind == RT_SHAPE_MESH) {
-                // Face.Collide on the recorded face, limited to the recorded distance: the same t again, and the barycentrics
-                const DMesh& mesh = sc.meshes[ch.index];
-                const double* pos = sc.prim_pos + (mesh.prim_off + leaf) * 9;
-                const V3 p0 = ld3(pos), p1 = ld3(pos + 3), p2 = ld3(pos + 6);
-                double t2, u, v;
-                ok = mt_core(lr, p0, p1, p2, 1e-8, kEps, t, t2, u, v);
-                h.prim = sc.prim_face[mesh.prim_off + leaf];
-                face_finish(lr, p0, p1, p2, sc.face_uv + (mesh.face_off + h.prim) * 6, t, u, v, h.c);
-            } else {
-                // Any other shape: k_walk kept the distance only.  The shape's Collide limited to that distance returns
-                // the same hit again (each returns its nearest root inside [tmin, tmax]).
-                ok = simple_collide(sc, ch.kind, ch.index, lr, kEps, t, h.c);
-                if (ok && ch.kind == RT_SHAPE_SPHERE && (ch.n > 0 || material_reads_uv(sc, nd.material))) sphere_uv(sc.spheres[ch.index], h.c);
-            }
-            if (!ok) {
-                atomicAdd(&C->errors.v, 1u);
-            } else {
-                if (ch.n > 0) chain_up(sc, ch, h.c);
-                if (terminal) add = terminal_emission(sc, m, h.c, ps.rad);
-                else want = true;
-            }
-        }
-        const V3 em2 = shade_lane<MODE == RT_MODE_FAST && !MESH_ONLY>(sc, pass, q, 1 - in, (stripe + k) & (kQueueStripes - 1), want, r, ps, h);
-        if (want) add = em2;
-        film_add_wave(film, ps.pixel, add);
+        const size_t first = (size_t)stripe * q.hit_stripe_cap + (size_t)k * kSortBlock;
+        int key = 4;
+        if (k * (uint32_t)kSortBlock + tid < n_s && hq.ray[first + tid] != kNoRay) key = sc.sort_kinds ? material_key(sc, hq.node[first + tid]) : 0;
+        int total;
+        const int src = block_order(key, total);
+        if (total == 0) continue;
+        const bool live = src >= 0;
+        const size_t at = first + (size_t)(live ? src : 0);
+        shade_record<MODE, MESH_ONLY>(sc, pass, q, in, (stripe + 4u * k + wave) & (kQueueStripes - 1), live, live ? hq.ray[at] : kNoRay, live ? hq.node[at] : 0,
+                                      live ? hq.leaf[at] : -1, live ? hq.t[at] : 0.0, film);
     }
 }
 
@@ -1594,13 +1650,13 @@ static inline size_t stack_bytes(const DScene& sc, int mode) {
 // Resident single-wave workgroups of a k_primary variant on the current device, rounded down to whole
 // rounds over the 8 XCDs.
 template <typename K>
-static unsigned persistent_grid(K kernel, size_t lds) {
+static unsigned persistent_grid(K kernel, size_t lds, int block = kTraceBlock) {
     // the answer depends only on (device, kernel, LDS bytes)
     static std::mutex mutex;
-    static std::map<std::tuple<const void*, int, size_t>, unsigned> cache;
+    static std::map<std::tuple<const void*, int, size_t, int>, unsigned> cache;
     int device = 0;
     (void)hipGetDevice(&device);
-    const auto key = std::make_tuple(reinterpret_cast<const void*>(kernel), device, lds);
+    const auto key = std::make_tuple(reinterpret_cast<const void*>(kernel), device, lds, block);
     {
         std::lock_guard<std::mutex> lock(mutex);
         const auto it = cache.find(key);
@@ -1608,7 +1664,7 @@ static unsigned persistent_grid(K kernel, size_t lds) {
     }
     int cus = 0, per_cu = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kTraceBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) per_cu = block == kTraceBlock ? 4 : 1;
     if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] persistent kernel %p: %d CUs x %d workgroups, %zu B LDS each\n", reinterpret_cast<const void*>(kernel), cus, per_cu, lds);
     const unsigned n = ((unsigned)std::max(cus, 8) * (unsigned)per_cu) & ~7u;
     std::lock_guard<std::mutex> lock(mutex);
@@ -1678,9 +1734,9 @@ void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int i
         const unsigned waves = std::max(1u, std::min(persistent_grid(kernel, lds), want_waves));
         hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), lds, s, sc, q, in, n, n_stripes);
     };
-    auto shade = [&](auto kernel) {
-        const unsigned waves = std::max(1u, std::min(persistent_grid(kernel, 0), want_waves + (unsigned)kQueueStripes));
-        hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), 0, s, sc, pass, q, in, film);
+    auto shade = [&](auto kernel) {  // workgroups of four waves
+        const unsigned groups = std::max(1u, std::min(persistent_grid(kernel, 0, kSortBlock), (want_waves + 3u) / 4u + (unsigned)kQueueStripes));
+        hipLaunchKernelGGL(kernel, dim3(groups), dim3(kSortBlock), 0, s, sc, pass, q, in, film);
     };
     if (mode == RT_MODE_REFERENCE) {
         if (mesh_only) { walk(k_walk<RT_MODE_REFERENCE, true, 2>); shade(k_shade<RT_MODE_REFERENCE, true, 2>); }

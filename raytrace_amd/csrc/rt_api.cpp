@@ -537,6 +537,14 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     DScene proto{};
     proto.n_walk_nodes = (int32_t)walk_nodes.size();
     proto.early_miss = std::getenv("RT_NO_EARLY_MISS") == nullptr ? 1 : 0;
+    {   // kinds of Material.Resolve code among the nodes' materials (the three that scatter, and "only emits")
+        unsigned kinds = 0;
+        for (const DNode& n : nodes) {
+            const int k = materials[(size_t)n.material].kind;
+            kinds |= 1u << (k == RT_MAT_LAMBERTIAN ? 0 : (k == RT_MAT_METAL ? 1 : (k == RT_MAT_DIELECTRIC ? 2 : 3)));
+        }
+        proto.sort_kinds = ((kinds & (kinds - 1)) != 0 && std::getenv("RT_NO_KIND_SORT") == nullptr) ? 1 : 0;
+    }
     if (d->n_nodes <= 64)
         for (int32_t i : walk_nodes) proto.walk_mask |= 1ull << i;
     proto.n_nodes = (int32_t)d->n_nodes;
