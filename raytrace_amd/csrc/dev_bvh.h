@@ -400,9 +400,6 @@ struct WalkLane {
 #ifndef RT_WALK_RING
 #define RT_WALK_RING 8
 #endif
-#ifndef RT_WALK_BREAK
-#define RT_WALK_BREAK 0
-#endif
 constexpr int kWalkRing = RT_WALK_RING;
 static_assert((kWalkRing & (kWalkRing - 1)) == 0, "the ring index is a mask");
 struct WalkStack {
@@ -582,9 +579,9 @@ RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin
             overflow = true;  // the host sizes the stack from the deepest tree: cannot happen, but must not pass silently
         }
     };
-#if RT_WALK_BREAK
-    const int entry_n = __popcll(__builtin_amdgcn_ballot_w64(true));
-#endif
+    // DScene::walk_break (per cent, 0 = off): the round's descent ends once fewer than that share of the lanes that began it
+    // are still among inner nodes
+    const int stay_n = sc.walk_break ? __popcll(__builtin_amdgcn_ballot_w64(true)) * sc.walk_break : 0;
     while (w.cur >= 0) {
 #ifdef RT_VISIT_STATS
         w.steps++;
@@ -621,10 +618,8 @@ RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin
         } else {
             pop_next();
         }
-#if RT_WALK_BREAK
         // the few lanes still among inner nodes stop here and go on in the next round: the others' leaves are not kept waiting
-        if (__popcll(__builtin_amdgcn_ballot_w64(w.cur >= 0)) * 100 < entry_n * RT_WALK_BREAK) break;
-#endif
+        if (__popcll(__builtin_amdgcn_ballot_w64(w.cur >= 0)) * 100 < stay_n) break;
     }
     if (w.cur == kFastEmpty || w.cur >= 0) return;
     const uint32_t code = (uint32_t)~w.cur;

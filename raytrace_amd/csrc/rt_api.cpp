@@ -389,7 +389,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<FastNode> fast_nodes;
     std::vector<QNode> q_nodes;
     std::vector<Q4Node> q4_nodes;
-    int32_t walk_cap = 2;
+    int32_t walk_cap = 2, deepest_fast = 0;
     std::vector<double> prim_pos;
     std::vector<Tri32> prim_tri32;
     std::vector<int32_t> prim_face;
@@ -420,6 +420,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         q_nodes.insert(q_nodes.end(), b.q_nodes.begin(), b.q_nodes.end());
         q4_nodes.insert(q4_nodes.end(), b.q4_nodes.begin(), b.q4_nodes.end());
         walk_cap = std::max(walk_cap, std::max(b.fast_depth + 1, 3 * b.q4_depth + 1));
+        deepest_fast = std::max(deepest_fast, (int32_t)b.fast_depth);
         prim_pos.insert(prim_pos.end(), b.prim_pos.begin(), b.prim_pos.end());
         prim_tri32.insert(prim_tri32.end(), b.prim_tri32.begin(), b.prim_tri32.end());
         prim_face.insert(prim_face.end(), b.prim_face.begin(), b.prim_face.end());
@@ -551,6 +552,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     proto.n_lights = (int32_t)d->n_lights;
     proto.stack_pairs = stack_pairs;
     proto.walk_cap = walk_cap;
+    // measured: +3 % (328 k faces, 20 levels) and +8 % (21 M faces) on the scattered rays of a scan, -2 % on a 6 k-face teapot (13 levels)
+    proto.walk_break = deepest_fast >= 17 ? 15 : 0;
+    if (const char* e = std::getenv("RT_WALK_BREAK")) proto.walk_break = std::max(0, std::min(100, std::atoi(e)));
     proto.n_meshes = (int32_t)d->n_meshes;
     {   // bounds of every node that holds a mesh (directly or under transforms): rays that miss them never walk a tree
         bool any = false;

@@ -120,6 +120,10 @@ struct DScene {
     const int32_t* walk_nodes;
     uint64_t walk_mask;  // the same as bits, for scenes of at most 64 nodes (bit i: node i holds a mesh)
     int32_t early_miss;  // 1: a scattered ray that enters no node's bounds is settled where it is made (0 with RT_NO_EARLY_MISS set: it is queued like the others)
+    // k_walk, per cent: a round's descent to the next leaves ends once fewer than this share of its lanes are still among inner
+    // nodes (they go on in the next round); 0 = every lane reaches a leaf first.  Deep trees, where descents differ most in length.
+    int32_t walk_break;
+    int32_t pad_walk_break;
     int32_t sort_kinds;  // 1: the nodes' materials run more than one kind of Resolve code: hits are taken in the order of their materials (k_shade)
 };
 
