@@ -480,6 +480,46 @@ def test_rays_settled_where_they_are_made_change_nothing(name, monkeypatch):
     assert 0 < out[0][0].Stats.RaysLeftScene < out[0][0].Stats.TotalRays
 
 
+def _four_material_meshes(dx=120, dy=90, spp=8):
+    """Four small meshes -- Lambertian, Metal, Dielectric, Emitter -- over a Lambertian ground quad, two lights: the hits of a
+    generation of scattered rays run every kind of Material.Resolve."""
+    v, t = scenes.icosphere(3)
+    uv = np.abs(v[:, :2]) * 0.5
+    mats = [phys.Lambertian(phys.TextureUniform((0.7, 0.3, 0.2))), phys.Metal((0.8, 0.8, 0.7), 0.08), phys.Dielectric(1.5, 1.0, 0.03),
+            phys.Emitter(phys.TextureUniform((1.5, 1.4, 1.2)))]
+    nodes = [phys.Node("ground", phys.Quad((0.0, 0.0, -1.0), (0.0, 0.0, 1.0), 14.0, 14.0), phys.Lambertian(phys.TextureUniform((0.6, 0.6, 0.6))))]
+    for k, m in enumerate(mats):
+        c = np.array([2.2 * (k - 1.5), 0.6 * (k % 2), 0.0])
+        nodes.append(phys.Node(f"ball{k}", phys.NewMesh(scenes.faces_from(v * 0.95 + c, uv, t)), m))
+    cam = phys.PinholeCamera((-5.0, -9.0, -2.0), (0.0, -16.0, 1.5), (10.0, 0.0, 0.0), (0.0, 0.0, 7.5))
+    lights = [phys.PointLight((3.0, -4.0, 8.0), (30.0, 28.0, 25.0)), phys.PointLight((-5.0, -2.0, 6.0), (8.0, 9.0, 14.0))]
+    return phys.Scene(Camera=[cam], Node=nodes, Light=lights, RenderOptions=phys.RenderOptions(11, spp, 6, dx, dy))
+
+
+@pytest.mark.parametrize("knob,value", [("RT_NO_KIND_SORT", "1"), ("RT_WALK_BREAK", "60"), ("RT_WALK_BREAK", "0")])
+def test_hits_taken_in_material_order_and_shortened_descents_change_nothing(ob, knob, value, monkeypatch):
+    """k_shade takes the hits of a chunk in the order of their materials (RT_NO_KIND_SORT=1: as they come) and k_walk may end a
+    round's descent early (RT_WALK_BREAK, per cent).  Neither changes which rays are traced or what they return: same counters,
+    and images equal up to the order of the float64 sums; the default build against the oracle as well."""
+    sc = _four_material_meshes()
+    monkeypatch.delenv(knob, raising=False)
+    with phys.DeviceScene(sc) as dev, ob.OracleScene(sc) as orc:
+        base = dev.render(sc.Camera[0], sc.RenderOptions)
+        img, st, _, _ = orc.render(sc.Camera[0], sc.RenderOptions)
+    monkeypatch.setenv(knob, value)
+    with phys.DeviceScene(sc) as dev:
+        other = dev.render(sc.Camera[0], sc.RenderOptions)
+    for k in ("TotalRays", "RaysLeftScene", "RaysExceededDepth", "ShadowRays"):
+        assert getattr(base.Stats, k) == getattr(other.Stats, k), k
+    diff = np.abs(base.Image.astype(int) - other.Image.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())
+    assert abs(base.Stats.TotalRays - st.total_rays) <= 1e-3 * st.total_rays  # libm differences move a few rays across a decision
+    assert abs(base.Stats.RaysLeftScene - st.rays_left_scene) <= 1e-3 * st.total_rays
+    d2 = np.abs(base.Image.astype(int) - img.astype(int))
+    assert (d2 > 1).mean() < 5e-3, ((d2 > 1).mean(), d2.max())
+    assert base.Stats.TotalRays > 1.25 * sc.RenderOptions.Dx * sc.RenderOptions.Dy * sc.RenderOptions.RaysPerPixel  # generations did follow
+
+
 def test_more_lights_than_a_launch_can_address_are_refused():
     lights = [phys.PointLight((float(i), 0.0, 5.0), (1.0, 1.0, 1.0)) for i in range(2048)]
     sc = phys.Scene(Camera=[phys.OrthographicCamera((0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 2.0, 2.0)],
