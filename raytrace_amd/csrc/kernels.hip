@@ -546,11 +546,7 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
         at = c.at;
         const uint32_t x = ps.pixel % (uint32_t)pass.dx, row = ps.pixel / (uint32_t)pass.dx;
         Rng rng{pass.seed_lo, pass.seed_hi, (uint32_t)(pass.dy - 1 - (int)row) * (uint32_t)pass.dx + x, ps.sample, ps.path, ps.depth_n & 0xFFFFFFu};
-#ifdef RT_KO_RESOLVE
-        sct.n = 0; sct.emission = mk(0, 0, 0); sct.albedo = mk(0, 0, 0);
-#else
         resolve(sc, m, r.d, ps.rad, c, rng, sct);
-#endif
         emission = sct.emission;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -622,11 +618,7 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
         for (int k = 0; k < 2; k++) {
             const uint32_t at_stripe = k == 0 ? base + (uint32_t)__popcll(m0 & below) : base + n0 + (uint32_t)__popcll(m1 & below);
             const uint32_t slot = first + at_stripe;
-#ifdef RT_KO_CHILD_STORE
-            if (child_ok[k] && cls[k] == c && at_stripe < q.ray_stripe_cap && sct.rad[k].x == 123.456) {
-#else
-            if (child_ok[k] && cls[k] == c && at_stripe < q.ray_stripe_cap) {
-#endif  // the host sizes the launches so that a stripe never fills up, and checks the cursors
+            if (child_ok[k] && cls[k] == c && at_stripe < q.ray_stripe_cap) {  // the host sizes the launches so that a stripe never fills up, and checks the cursors
                 next.o[0][slot] = at.x; next.o[1][slot] = at.y; next.o[2][slot] = at.z;
                 next.d[0][slot] = sct.dir[k].x; next.d[1][slot] = sct.dir[k].y; next.d[2][slot] = sct.dir[k].z;
                 next.rad[0][slot] = sct.rad[k].x; next.rad[1][slot] = sct.rad[k].y; next.rad[2][slot] = sct.rad[k].z;
@@ -639,11 +631,7 @@ RT_DEV V3 shade_lane(const DScene& sc, const PassDesc& pass, const Queues& q, in
     }
     const uint32_t ss_stripe = wave_append(&q.counters->surf_cursor[stripe].v, want_surf);
     const uint32_t ss = stripe * q.surf_stripe_cap + ss_stripe;
-#ifdef RT_KO_SURF_STORE
-    if (want_surf && ss_stripe < q.surf_stripe_cap && at.x == 123.456) {
-#else
     if (want_surf && ss_stripe < q.surf_stripe_cap) {
-#endif
         q.surfs.p[0][ss] = at.x; q.surfs.p[1][ss] = at.y; q.surfs.p[2][ss] = at.z;
         q.surfs.n[0][ss] = s_n.x; q.surfs.n[1][ss] = s_n.y; q.surfs.n[2][ss] = s_n.z;
         q.surfs.wo[0][ss] = s_wo.x; q.surfs.wo[1][ss] = s_wo.y; q.surfs.wo[2][ss] = s_wo.z;
