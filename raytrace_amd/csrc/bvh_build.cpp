@@ -16,9 +16,33 @@
 #include <future>
 #include <limits>
 #include <memory>
+#include <thread>
+#include <vector>
 
 namespace rt {
 namespace {
+
+// Host threads for the passes over all faces of a large mesh (bounds, binning, partition, leaf-order copies).  A GPU box
+// gives a process a share of its CPUs, not all that hardware_concurrency() reports: 16 at most; RT_HOST_THREADS overrides.
+int host_threads() {
+    if (const char* e = std::getenv("RT_HOST_THREADS")) return std::max(1, std::min(64, std::atoi(e)));
+    static const int n = std::max(1, std::min((int)std::thread::hardware_concurrency(), 16));
+    return n;
+}
+
+// f(part, begin, end) over `parts` contiguous chunks of [lo, hi), one thread each (the caller's thread takes the last).
+template <class F>
+void parallel_chunks(uint64_t lo, uint64_t hi, int parts, F f) {
+    const uint64_t n = hi - lo;
+    parts = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)parts, n));
+    auto begin_of = [&](int p) { return lo + n * (uint64_t)p / (uint64_t)parts; };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)parts - 1);
+    for (int p = 0; p + 1 < parts; p++) pool.emplace_back([&, p] { f(p, begin_of(p), begin_of(p + 1)); });
+    f(parts - 1, begin_of(parts - 1), hi);
+    for (std::thread& t : pool) t.join();
+}
+constexpr uint64_t kWideFaces = 1u << 17;  // passes over at least this many faces are cut into chunks
 
 constexpr double kInf = std::numeric_limits<double>::infinity();
 constexpr int kMaxDepth = 32;         // shape_bvh.go:82
@@ -78,22 +102,42 @@ struct TreeNode {
 struct Builder {
     const Box* face_box;         // Face.Bounds(), shape_mesh.go:145-161
     std::vector<uint32_t> order; // shapes of the current recursion, partitioned in place
-    std::vector<uint32_t> scratch;
+    std::vector<uint32_t> scratch;  // the other buffer of the partition (recursions work on disjoint ranges of all three arrays)
+    std::vector<uint8_t> bin_at;    // bin of the shape at each position of `order`, from the binning pass of the node at hand
 
-    std::unique_ptr<TreeNode> build(uint32_t lo, uint32_t hi, int depth) {
+    // known: the union of the shapes' bounds when the parent already has it (the bins of its split hold it), else null
+    std::unique_ptr<TreeNode> build(uint32_t lo, uint32_t hi, int depth, const Box* known = nullptr) {
         const uint32_t n = hi - lo;
         auto node = std::make_unique<TreeNode>();
         node->depth = (uint32_t)depth;
         if (n == 1 || depth >= kMaxDepth || (int)n <= kMinShapesPerLeaf) {  // shape_bvh.go:91-108
             Box b = face_box[order[lo]];
-            for (uint32_t i = lo + 1; i < hi; i++) b = unite(b, face_box[order[i]]);
+            if (known) b = *known;
+            else for (uint32_t i = lo + 1; i < hi; i++) b = unite(b, face_box[order[i]]);
             node->box = b;
             node->first = lo;
             node->count = n;
             return node;
         }
+        // A node of very many shapes runs its three passes (bounds, binning, partition) in chunks on several threads.  Union
+        // and counting are associative and the partition keeps the order, so the tree is the same tree.
+        const bool wide = n >= kWideFaces && host_threads() > 1;
+        const int parts = wide ? host_threads() : 1;
         Box bbox = face_box[order[lo]];
-        for (uint32_t i = lo + 1; i < hi; i++) bbox = unite(bbox, face_box[order[i]]);
+        if (known) {
+            bbox = *known;
+        } else if (wide) {
+            std::vector<Box> part_box((size_t)parts, empty_box());
+            parallel_chunks(lo, hi, parts, [&](int p, uint64_t a, uint64_t e) {
+                Box b = face_box[order[a]];
+                for (uint64_t i = a + 1; i < e; i++) b = unite(b, face_box[order[i]]);
+                part_box[(size_t)p] = b;
+            });
+            bbox = part_box[0];
+            for (int p = 1; p < parts; p++) bbox = unite(bbox, part_box[(size_t)p]);
+        } else {
+            for (uint32_t i = lo + 1; i < hi; i++) bbox = unite(bbox, face_box[order[i]]);
+        }
         node->box = bbox;
         const int axis = longest_axis(bbox);
         const double bmin = bbox.mn[axis], bmax = bbox.mx[axis];
@@ -106,8 +150,27 @@ struct Builder {
         };
         struct Bin { Box b; int count; } bins[kBins];
         for (auto& b : bins) { b.b = empty_box(); b.count = 0; }
+        if (wide) {
+            std::vector<Bin> part_bins((size_t)parts * kBins);
+            parallel_chunks(lo, hi, parts, [&](int p, uint64_t a, uint64_t e) {
+                Bin* mine = part_bins.data() + (size_t)p * kBins;
+                for (int k = 0; k < kBins; k++) { mine[k].b = empty_box(); mine[k].count = 0; }
+                for (uint64_t i = a; i < e; i++) {
+                    const int bi = bin_of(centroid(order[i]));
+                    bin_at[i] = (uint8_t)bi;
+                    mine[bi].count++;
+                    mine[bi].b = unite(mine[bi].b, face_box[order[i]]);
+                }
+            });
+            for (int p = 0; p < parts; p++)
+                for (int k = 0; k < kBins; k++) {
+                    bins[k].count += part_bins[(size_t)p * kBins + k].count;
+                    bins[k].b = unite(bins[k].b, part_bins[(size_t)p * kBins + k].b);
+                }
+        } else
         for (uint32_t i = lo; i < hi; i++) {
             int bi = bin_of(centroid(order[i]));
+            bin_at[i] = (uint8_t)bi;
             bins[bi].count++;
             bins[bi].b = unite(bins[bi].b, face_box[order[i]]);
         }
@@ -135,18 +198,47 @@ struct Builder {
             std::stable_sort(order.begin() + lo, order.begin() + hi,
                              [&](uint32_t a, uint32_t b) { return centroid(a) < centroid(b); });
             mid = lo + n / 2;
-        } else {  // shape_bvh.go:233-246: order-preserving split
-            auto it = std::stable_partition(order.begin() + lo, order.begin() + hi,
-                                            [&](uint32_t f) { return bin_of(centroid(f)) <= best_split; });
-            mid = (uint32_t)(it - order.begin());
+        } else if (wide) {  // the same order-preserving split: every chunk knows where its left and right shapes go
+            std::vector<uint32_t> lefts((size_t)parts + 1, 0), rights((size_t)parts + 1, 0);
+            parallel_chunks(lo, hi, parts, [&](int p, uint64_t a, uint64_t e) {
+                uint32_t l = 0;
+                for (uint64_t i = a; i < e; i++) l += bin_at[i] <= best_split ? 1u : 0u;
+                lefts[(size_t)p + 1] = l;
+                rights[(size_t)p + 1] = (uint32_t)(e - a) - l;
+            });
+            for (int p = 0; p < parts; p++) { lefts[(size_t)p + 1] += lefts[(size_t)p]; rights[(size_t)p + 1] += rights[(size_t)p]; }
+            mid = lo + lefts[(size_t)parts];
+            parallel_chunks(lo, hi, parts, [&](int p, uint64_t a, uint64_t e) {
+                uint32_t l = lo + lefts[(size_t)p], r = mid + rights[(size_t)p];
+                for (uint64_t i = a; i < e; i++) {
+                    if (bin_at[i] <= best_split) scratch[l++] = order[i];
+                    else scratch[r++] = order[i];
+                }
+            });
+            parallel_chunks(lo, hi, parts, [&](int, uint64_t a, uint64_t e) { std::memcpy(order.data() + a, scratch.data() + a, (e - a) * sizeof(uint32_t)); });
+        } else {  // shape_bvh.go:233-246: order-preserving split (the bins are those of the binning pass)
+            uint32_t l = lo;
+            for (uint32_t i = lo; i < hi; i++) l += bin_at[i] <= best_split ? 1u : 0u;
+            mid = l;
+            uint32_t r = mid;
+            l = lo;
+            for (uint32_t i = lo; i < hi; i++) {
+                if (bin_at[i] <= best_split) scratch[l++] = order[i];
+                else scratch[r++] = order[i];
+            }
+            std::memcpy(order.data() + lo, scratch.data() + lo, (size_t)n * sizeof(uint32_t));
         }
+        // A bin's box is the union of its shapes' bounds and unions are exact, so the two sides of a bin split already have
+        // theirs (what the reference recomputes at the top of the recursion, shape_bvh.go:110-114).
+        const Box* left_box = best_split >= 0 ? &lb[best_split] : nullptr;
+        const Box* right_box = best_split >= 0 ? &rb[best_split + 1] : nullptr;
         if (n > 32768 && depth < 5) {  // the reference forks two goroutines per split (shape_bvh.go:249-261)
-            auto fut = std::async(std::launch::async, [&, lo, mid, depth] { return build(lo, mid, depth + 1); });
-            node->right = build(mid, hi, depth + 1);
+            auto fut = std::async(std::launch::async, [&, lo, mid, depth, left_box] { return build(lo, mid, depth + 1, left_box); });
+            node->right = build(mid, hi, depth + 1, right_box);
             node->left = fut.get();
         } else {
-            node->left = build(lo, mid, depth + 1);
-            node->right = build(mid, hi, depth + 1);
+            node->left = build(lo, mid, depth + 1, left_box);
+            node->right = build(mid, hi, depth + 1, right_box);
         }
         return node;
     }
@@ -271,25 +363,42 @@ struct Flattener {
 
 void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<Box> boxes(n_faces);
-    for (uint64_t i = 0; i < n_faces; i++) {
-        const rt_face& f = faces[i];
-        for (int k = 0; k < 3; k++) {
-            boxes[i].mn[k] = gmin(gmin(f.v[0][k], f.v[1][k]), f.v[2][k]);
-            boxes[i].mx[k] = gmax(gmax(f.v[0][k], f.v[1][k]), f.v[2][k]);
+    auto t_last = t0;
+    const bool debug = std::getenv("RT_DEBUG") != nullptr && n_faces > 100000;
+    auto stage = [&](const char* what) {
+        if (!debug) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rt] build_mesh_bvh %-22s %7.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
+    const int threads = n_faces >= kWideFaces ? host_threads() : 1;
+    std::unique_ptr<Box[]> boxes(new Box[n_faces]);  // not a vector: its pages are first touched by the threads that fill them
+    parallel_chunks(0, n_faces, threads, [&](int, uint64_t a, uint64_t e) {
+        for (uint64_t i = a; i < e; i++) {
+            const rt_face& f = faces[i];
+            for (int k = 0; k < 3; k++) {
+                boxes[i].mn[k] = gmin(gmin(f.v[0][k], f.v[1][k]), f.v[2][k]);
+                boxes[i].mx[k] = gmax(gmax(f.v[0][k], f.v[1][k]), f.v[2][k]);
+            }
         }
-    }
+    });
+    stage("face bounds");
     Builder b;
-    b.face_box = boxes.data();
+    b.face_box = boxes.get();
     b.order.resize(n_faces);
     for (uint64_t i = 0; i < n_faces; i++) b.order[i] = (uint32_t)i;
+    b.scratch.resize(n_faces);
+    b.bin_at.resize(n_faces);
     std::unique_ptr<TreeNode> root = b.build(0, (uint32_t)n_faces, 0);
+    stage("NewBVH");
 
     out.ref_nodes.clear();
     out.fast_nodes.clear();
     out.ref_nodes.reserve(n_faces);
     Flattener fl{out};
-    fl.ref(root.get());
+    // The reference-order nodes, the traversal trees and the faces in leaf order are written from the finished tree
+    // independently of each other (different arrays, different members of the flattener): three threads.
+    std::thread ref_thread([&] { fl.ref(root.get()); });
 
     double radius = 0;
     for (int k = 0; k < 3; k++) {
@@ -300,7 +409,33 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
     }
     out.pad = round_up(radius * kBoxPad);
     out.radius = (float)radius;
-    fl.face_box = boxes.data();
+    std::thread prim_thread([&] {
+    out.prim_face.resize(n_faces);
+    out.prim_pos.resize(n_faces * 9);
+    out.prim_tri32.resize(n_faces);
+    parallel_chunks(0, n_faces, threads, [&](int, uint64_t pa, uint64_t pe) {
+    for (uint64_t i = pa; i < pe; i++) {
+        const uint32_t fi = b.order[i];
+        out.prim_face[i] = (int32_t)fi;
+        for (int v = 0; v < 3; v++)
+            for (int k = 0; k < 3; k++) out.prim_pos[i * 9 + v * 3 + k] = faces[fi].v[v][k];
+        Tri32& t = out.prim_tri32[i];
+        double l1 = 0, l2 = 0;
+        for (int k = 0; k < 3; k++) {
+            const double e1 = faces[fi].v[1][k] - faces[fi].v[0][k], e2 = faces[fi].v[2][k] - faces[fi].v[0][k];
+            t.p0[k] = (float)(faces[fi].v[0][k] - out.center[k]);
+            t.e1[k] = (float)e1;
+            t.e2[k] = (float)e2;
+            l1 += e1 * e1;
+            l2 += e2 * e2;
+        }
+        t.len1 = round_up(std::sqrt(l1));
+        t.len2 = round_up(std::sqrt(l2));
+        t.pad = 0;
+    }
+    });
+    });
+    fl.face_box = boxes.get();
     fl.order = b.order.data();
     out.fast_nodes.reserve(n_faces + 1);
     if (root->left) {
@@ -316,6 +451,7 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
         out.fast_nodes[0] = f;
     }
 
+    stage("fast tree");
     // The quantised copy of the tree.  The grid spans the union of all child boxes (they carry the padding), widened a little.
     {
         float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -335,7 +471,8 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
             out.grid_step[a] = round_up((double)(hi[a] + 4.0f * ext / 65535.0f - out.grid_lo[a]) / 65520.0);  // every plane lands inside [8, 65528)
         }
         out.q_nodes.resize(out.fast_nodes.size());
-        for (size_t i = 0; i < out.fast_nodes.size(); i++) {
+        parallel_chunks(0, out.fast_nodes.size(), threads, [&](int, uint64_t qa, uint64_t qe) {
+        for (size_t i = qa; i < qe; i++) {
             const FastNode& f = out.fast_nodes[i];
             QNode& qn = out.q_nodes[i];
             for (int k = 0; k < 2; k++) {
@@ -351,8 +488,10 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
                 }
             }
         }
+        });
     }
 
+    stage("quantised nodes");
     // Two levels per node.  Built without recursion (a work list of (binary node, slot to patch)): trees of scans are deep.
     {
         out.q4_nodes.clear();
@@ -426,29 +565,11 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
         }
     }
 
+    stage("four-wide nodes");
     out.fast_depth = std::max(fl.fast_depth, 1);
-    out.prim_face.resize(n_faces);
-    out.prim_pos.resize(n_faces * 9);
-    out.prim_tri32.resize(n_faces);
-    for (uint64_t i = 0; i < n_faces; i++) {
-        const uint32_t fi = b.order[i];
-        out.prim_face[i] = (int32_t)fi;
-        for (int v = 0; v < 3; v++)
-            for (int k = 0; k < 3; k++) out.prim_pos[i * 9 + v * 3 + k] = faces[fi].v[v][k];
-        Tri32& t = out.prim_tri32[i];
-        double l1 = 0, l2 = 0;
-        for (int k = 0; k < 3; k++) {
-            const double e1 = faces[fi].v[1][k] - faces[fi].v[0][k], e2 = faces[fi].v[2][k] - faces[fi].v[0][k];
-            t.p0[k] = (float)(faces[fi].v[0][k] - out.center[k]);
-            t.e1[k] = (float)e1;
-            t.e2[k] = (float)e2;
-            l1 += e1 * e1;
-            l2 += e2 * e2;
-        }
-        t.len1 = round_up(std::sqrt(l1));
-        t.len2 = round_up(std::sqrt(l2));
-        t.pad = 0;
-    }
+    prim_thread.join();
+    ref_thread.join();
+    stage("joined the other two");
     out.info.n_faces = n_faces;
     out.info.n_nodes = out.ref_nodes.size();
     out.info.n_leaves = fl.leaves;

@@ -415,15 +415,20 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         std::memcpy(m.grid_lo, b.grid_lo, sizeof(m.grid_lo));
         std::memcpy(m.grid_step, b.grid_step, sizeof(m.grid_step));
         m.n_faces = (int32_t)d->meshes[i].n_faces;
-        ref_nodes.insert(ref_nodes.end(), b.ref_nodes.begin(), b.ref_nodes.end());
-        fast_nodes.insert(fast_nodes.end(), b.fast_nodes.begin(), b.fast_nodes.end());
-        q_nodes.insert(q_nodes.end(), b.q_nodes.begin(), b.q_nodes.end());
-        q4_nodes.insert(q4_nodes.end(), b.q4_nodes.begin(), b.q4_nodes.end());
+        // the first mesh hands its arrays over (a scan is one mesh of hundreds of megabytes), the others are appended
+        auto take = [](auto& all, auto& part) {
+            if (all.empty()) all = std::move(part);
+            else all.insert(all.end(), part.begin(), part.end());
+        };
+        take(ref_nodes, b.ref_nodes);
+        take(fast_nodes, b.fast_nodes);
+        take(q_nodes, b.q_nodes);
+        take(q4_nodes, b.q4_nodes);
         walk_cap = std::max(walk_cap, std::max(b.fast_depth + 1, 3 * b.q4_depth + 1));
         deepest_fast = std::max(deepest_fast, (int32_t)b.fast_depth);
-        prim_pos.insert(prim_pos.end(), b.prim_pos.begin(), b.prim_pos.end());
-        prim_tri32.insert(prim_tri32.end(), b.prim_tri32.begin(), b.prim_tri32.end());
-        prim_face.insert(prim_face.end(), b.prim_face.begin(), b.prim_face.end());
+        take(prim_pos, b.prim_pos);
+        take(prim_tri32, b.prim_tri32);
+        take(prim_face, b.prim_face);
         sc->bvh_info[i] = b.info;
         stack_pairs = std::max(stack_pairs, b.fast_depth + 1);
     }

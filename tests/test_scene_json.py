@@ -205,6 +205,27 @@ def test_exported_bvh_is_the_tree_the_oracle_builds(faces):
     assert len(tree) == nodes and sorted(leaf.tolist()) == list(range(len(faces)))
 
 
+def test_threaded_passes_of_the_builder_give_the_same_tree(monkeypatch):
+    """Nodes of 131 072 or more faces run their bounds, binning and partition passes in chunks on several threads, and the
+    flattened arrays are written by three threads side by side: the tree must be the one a single thread builds, node for
+    node and face for face, whatever the number of chunks, and have the oracle's counts."""
+    from oracle import binding
+    faces = scenes.scan_standin_mesh(level=7)  # 327 680 faces: the root and its children are wide nodes
+    out = []
+    for threads in ("1", "7", "16"):
+        monkeypatch.setenv("RT_HOST_THREADS", threads)
+        tree, leaf = J.mesh_bvh(faces)
+        out.append((tree.tobytes(), leaf.tobytes(), len(tree)))
+    assert out[0] == out[1] == out[2]
+    sc = phys.Scene(Camera=[phys.OrthographicCamera((0, 0, 500), (0, 0, 0), (0, 1, 0), 250.0, 250.0)],
+                    Node=[phys.Node("m", phys.Mesh(faces), phys.DebugNormal())], RenderOptions=phys.RenderOptions(0, 1, 1, 4, 4))
+    with binding.OracleScene(sc) as orc:
+        info = orc.bvh_info(0)
+    tree = np.frombuffer(out[0][0], dtype=abi.BVH_NODE_DTYPE)
+    assert len(tree) == info.n_nodes and int((tree["right"] < 0).sum()) == info.n_leaves
+    assert int(tree["count"].max()) == info.max_leaf_size
+
+
 def test_image_pixels_can_come_from_the_file_path(tmp_path):
     """A TextureImage written without pixels ("Image": null) is loaded again from FilePath, the field the
     reference keeps "for serialization" (texture_image.go:20)."""
