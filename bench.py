@@ -5,9 +5,10 @@ Workload (the configuration the headline metric is quoted on): the scan stand-in
 (icosphere level 8, 1,310,720 faces; the real einstein.obj is not available), Emitter +
 4096^2 bilinear image texture, orthographic camera of example/scan, 3840x2160, 1024 rays per
 pixel, fast mode.  One "step" renders `--spp-step` consecutive sample indices of every pixel of
-the frame (default 256, so 4 steps are the whole 1024-spp frame); the rows of the frame are cut
-into 16-row bands dealt round-robin to the ranks, every rank keeps the whole scene in its own
-HBM, and the per-rank films are gathered onto rank 0 with one RCCL gather after the last step.
+the frame (default 1024: a step is the whole frame, one launch of the primary kernel per rank);
+the rows of the frame are cut into 16-row bands dealt round-robin to the ranks, every rank keeps
+the whole scene in its own HBM, and the per-rank films are gathered onto rank 0 with one RCCL
+gather after the last step.
 
 Prints ONE JSON line on rank 0.  `value` is TotalRays (the reference's RenderStats counter,
 render.go:143) of all ranks divided by the slowest rank's wall time for the K timed steps, with
@@ -36,7 +37,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=4)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--spp-step", type=int, default=256, help="sample indices rendered per step")
+    p.add_argument("--spp-step", type=int, default=1024, help="sample indices rendered per step (default: all of the frame's, one launch)")
     p.add_argument("--level", type=int, default=8, help="icosphere level of the stand-in mesh (8 = 1.31 M faces)")
     p.add_argument("--dx", type=int, default=3840)
     p.add_argument("--dy", type=int, default=2160)
@@ -136,6 +137,8 @@ def main():
         cnt = min(a.spp_step, o.RaysPerPixel - s0)
         ro = phys.render_opts(o, abi.MODE_FAST, rank, a.emulate_world or world, stream, s0, cnt)
         st = abi.Stats()
+        if s0 == 0:
+            film.zero_()  # a new frame begins (part of the step, as in rt_render)
         # RT_NO_PIXEL_CULL is read by the library at every call: set = every tile is traced
         if culling:
             os.environ.pop("RT_NO_PIXEL_CULL", None)
