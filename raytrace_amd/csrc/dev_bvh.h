@@ -13,8 +13,9 @@ struct VisitCounts {
     bool overflow = false;
 #ifdef RT_VISIT_STATS
     // per-lane walk, diagnostics: [0] walks of the wave, [1] lanes in them, [2] inner-node steps of the wave, [3] lanes in
-    // them, [4] face steps, [5] lanes in them; [6..11] the same for any-hit walks (all wave-uniform sums)
-    uint32_t w[12] = {};
+    // them, [4] face steps, [5] lanes in them; [6..11] the same for any-hit walks (all wave-uniform sums); k_walk's rounds use
+    // [0..5] the same way (face steps = float32 pre-tests) and [12] float64 face steps, [13] lanes in them
+    uint32_t w[16] = {};
 #endif
 };
 
@@ -27,7 +28,7 @@ __device__ unsigned long long g_trace_stats[64][64];   // k_trace / k_direct, st
 #define RT_WSTAT(i, n) do { cnt.w[(ANY_HIT ? 6 : 0) + (i)] += (uint32_t)(n); } while (0)
 #define RT_FIRST_ACTIVE (((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) ? 1 : 0)
 // every lane adds its own tallies (first-active-lane tallies add up to the wave's step counts)
-#define RT_WFLUSH(c) do { for (int k_ = 0; k_ < 12; k_++) if ((c).w[k_]) atomicAdd(&g_trace_stats[(blockIdx.x + threadIdx.x) & 63u][16 + k_], (unsigned long long)(c).w[k_]); } while (0)
+#define RT_WFLUSH(c) do { for (int k_ = 0; k_ < 16; k_++) if ((c).w[k_]) atomicAdd(&g_trace_stats[(blockIdx.x + threadIdx.x) & 63u][16 + k_], (unsigned long long)(c).w[k_]); } while (0)
 #else
 #define RT_STAT(i, n) do { } while (0)
 #define RT_TSTAT(i, n) do { } while (0)
@@ -539,7 +540,14 @@ RT_DEV void walk_round(const DScene& sc, WalkLane& w, int32_t node, double tmin,
 // four) children a ray reaches are sorted by entry distance; the nearest is visited next, the others are pushed farthest
 // first.  WalkLane::node_base must then be the mesh's first Q4Node.
 template <bool ANY_HIT, int RING>
-RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin, BestHit& best, const WalkStack& st, bool& overflow) {
+RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin, BestHit& best, const WalkStack& st, bool& overflow
+#ifdef RT_VISIT_STATS
+                        , uint32_t* ws
+#endif
+) {
+#ifdef RT_VISIT_STATS
+    ws[0] += RT_FIRST_ACTIVE; ws[1] += 1;
+#endif
     const Q4Node* nodes = sc.q4_nodes + w.node_base;
     const double* pos = sc.prim_pos + (size_t)w.prim_base * 9;
     const Tri32* tri32 = sc.prim_tri32 + w.prim_base;
@@ -585,6 +593,7 @@ RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin
     while (w.cur >= 0) {
 #ifdef RT_VISIT_STATS
         w.steps++;
+        ws[2] += RT_FIRST_ACTIVE; ws[3] += 1;
 #endif
         const Q4Node n = nodes[w.cur];
         float tn[4];
@@ -626,9 +635,16 @@ RT_DEV void walk_round4(const DScene& sc, WalkLane& w, int32_t node, double tmin
     const int32_t first = (int32_t)(code >> 3);
     const int32_t count = (int32_t)(code & 7u) + 1;
     uint32_t pending = 0;  // pre-tests of the whole leaf first, then the float64 tests of the survivors (see walk_round)
-    for (int32_t q = 0; q < count; q++)
+    for (int32_t q = 0; q < count; q++) {
+#ifdef RT_VISIT_STATS
+        ws[4] += RT_FIRST_ACTIVE; ws[5] += 1;
+#endif
         if (!tri32_rejects(tri32[first + q], f, w.dx, w.dy, w.dz, w.err_r, w.err_d)) pending |= 1u << q;
+    }
     while (pending != 0) {
+#ifdef RT_VISIT_STATS
+        ws[12] += RT_FIRST_ACTIVE; ws[13] += 1;
+#endif
         const int32_t face = first + (__builtin_ffs((int)pending) - 1);
         pending &= pending - 1;
         const double* p = pos + (int64_t)face * 9;

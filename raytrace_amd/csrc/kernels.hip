@@ -1255,7 +1255,11 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_walk(DScene sc, Queues q
 #ifdef RT_WALK_BINARY
                 walk_round<false, kWalkRing>(sc, w, walk_node, kEps, best, stack, vc.overflow);
 #else
+#ifdef RT_VISIT_STATS
+                walk_round4<false, kWalkRing>(sc, w, walk_node, kEps, best, stack, vc.overflow, vc.w);
+#else
                 walk_round4<false, kWalkRing>(sc, w, walk_node, kEps, best, stack, vc.overflow);
+#endif
 #endif
                 if (w.cur == kFastEmpty && sc.n_walk_nodes > 1) {  // this tree is done: on to the next one the ray can reach
                     walk_k++;
@@ -1322,6 +1326,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_walk(DScene sc, Queues q
     // the rest of the last block of hit records stays unused
     for (uint32_t i = out_pos + (uint32_t)lane; i < out_end; i += 64) hq.ray[(size_t)out_stripe * q.hit_stripe_cap + i] = kNoRay;
     wave_tally(C, 0, n_left, 0);  // the rays of this launch themselves are counted by the host
+    RT_WFLUSH(vc);
     report_overflow(C, vc);
 }
 

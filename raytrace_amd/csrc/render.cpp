@@ -802,6 +802,8 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 ts[8], d(ts[9], ts[8]), d(ts[11], ts[8]), d(ts[10], ts[8]), d(ts[12], ts[8]), d(ts[13], ts[8]));
         fprintf(stderr, "[rt] per-lane closest walks: %llu waves at %.1f lanes; per wave %.1f inner steps at %.1f lanes, %.1f face steps at %.1f lanes\n",
                 ts[16], d(ts[17], ts[16]), d(ts[18], ts[16]), d(ts[19], ts[18]), d(ts[20], ts[16]), d(ts[21], ts[20]));
+        fprintf(stderr, "[rt] k_walk rounds: %llu at %.1f lanes; per round %.2f descent steps at %.1f lanes, %.2f float32 face steps at %.1f lanes, %.2f float64 face steps at %.1f lanes\n",
+                ts[16], d(ts[17], ts[16]), d(ts[18], ts[16]), d(ts[19], ts[18]), d(ts[20], ts[16]), d(ts[21], ts[20]), d(ts[28], ts[16]), d(ts[29], ts[28]));
         fprintf(stderr, "[rt] per-lane any-hit walks: %llu waves at %.1f lanes; per wave %.1f inner steps at %.1f lanes, %.1f face steps at %.1f lanes\n",
                 ts[22], d(ts[23], ts[22]), d(ts[24], ts[22]), d(ts[25], ts[24]), d(ts[26], ts[22]), d(ts[27], ts[26]));
         fprintf(stderr, "[rt] share of round cycles: ray generation %.1f %%, closest hit (set-up + walk) %.1f %%, rest (attributes, shading, film) %.1f %%\n",
