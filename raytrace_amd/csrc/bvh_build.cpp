@@ -290,6 +290,9 @@ struct Flattener {
     }
     static int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
+    std::vector<FastNode>* dst = nullptr;  // the tree fast() writes: out.fast_nodes or out.beam_nodes
+    uint32_t merge_faces = 0;              // > 0: a subtree of at most that many faces becomes one leaf
+
     // A run of prims that is too long for one leaf reference: halve it under extra nodes.
     int32_t fast_depth = 0, cur_depth = 0;
     struct DepthScope {
@@ -301,48 +304,79 @@ struct Flattener {
     int32_t chunk(uint32_t first, uint32_t count) {
         if (count <= 8) return leaf_ref(first, count);
         DepthScope scope(*this);
-        const int32_t me = (int32_t)out.fast_nodes.size();
-        out.fast_nodes.emplace_back();
+        const int32_t me = (int32_t)(*dst).size();
+        (*dst).emplace_back();
         const uint32_t half = count / 2;
         const uint32_t f0[2] = {first, first + half}, c0[2] = {half, count - half};
         for (int k = 0; k < 2; k++) {
             const Box b = range_box(f0[k], c0[k]);
             const int32_t ref = never_hit(b) ? kFastEmpty : chunk(f0[k], c0[k]);
-            FastNode f = out.fast_nodes[me];
+            FastNode f = (*dst)[me];
             set_box(f, k, b);
             f.child[k] = ref;
             if (ref == kFastEmpty) set_empty(f, k);
-            out.fast_nodes[me] = f;
+            (*dst)[me] = f;
         }
         return me;
+    }
+
+    // Faces of a subtree (a contiguous run in leaf order); false when there are more than `limit` or a box in it can never be entered.
+    bool span(const TreeNode* c, uint32_t limit, uint32_t& first, uint32_t& count) const {
+        if (never_hit(c->box)) return false;
+        if (!c->left) {
+            if (count == 0) first = c->first;
+            count += c->count;
+            return count <= limit;
+        }
+        return span(c->left.get(), limit, first, count) && span(c->right.get(), limit, first, count);
     }
 
     int32_t child_ref(const TreeNode* c) {
         if (never_hit(c->box)) return kFastEmpty;
         if (!c->left) return chunk(c->first, c->count);
+        if (merge_faces > 0) {
+            uint32_t first = 0, count = 0;
+            if (span(c, merge_faces, first, count)) return leaf_ref(first, count);
+        }
         return fast(c);
     }
 
     int32_t fast(const TreeNode* n) {  // n is an inner node
         DepthScope scope(*this);
-        const int32_t me = (int32_t)out.fast_nodes.size();
-        out.fast_nodes.emplace_back();
+        const int32_t me = (int32_t)(*dst).size();
+        (*dst).emplace_back();
         const TreeNode* kids[2] = {n->left.get(), n->right.get()};
         for (int k = 0; k < 2; k++) {
             const int32_t ref = child_ref(kids[k]);  // may grow (reallocate) fast_nodes
-            FastNode f = out.fast_nodes[me];
+            FastNode f = (*dst)[me];
             set_box(f, k, kids[k]->box);
             f.child[k] = ref;
             if (ref == kFastEmpty) set_empty(f, k);
-            out.fast_nodes[me] = f;
+            (*dst)[me] = f;
         }
         return me;
+    }
+
+    // The whole traversal tree under `root` into *dst.
+    void tree(const TreeNode* root) {
+        if (root->left) {
+            fast(root);
+        } else {  // the whole mesh is one leaf: give it a parent so traversal has a node to start from
+            dst->emplace_back();
+            const int32_t ref = child_ref(root);
+            FastNode f = (*dst)[0];
+            set_box(f, 0, root->box);
+            f.child[0] = ref;
+            if (ref == kFastEmpty) set_empty(f, 0);
+            set_empty(f, 1);
+            (*dst)[0] = f;
+        }
     }
 };
 
 }  // namespace
 
-void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
+void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out, bool want_beam_tree) {
     auto t0 = std::chrono::steady_clock::now();
     auto t_last = t0;
     const bool debug = std::getenv("RT_DEBUG") != nullptr && n_faces > 100000;
@@ -418,23 +452,31 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
     });
     fl.face_box = boxes.get();
     fl.order = b.order.data();
+    fl.dst = &out.fast_nodes;
     out.fast_nodes.reserve(n_faces + 1);
-    if (root->left) {
-        fl.fast(root.get());
-    } else {  // the whole mesh is one leaf: give it a parent so traversal has a node to start from
-        out.fast_nodes.emplace_back();
-        const int32_t ref = fl.child_ref(root.get());
-        FastNode f = out.fast_nodes[0];
-        fl.set_box(f, 0, root->box);
-        f.child[0] = ref;
-        if (ref == kFastEmpty) Flattener::set_empty(f, 0);
-        Flattener::set_empty(f, 1);
-        out.fast_nodes[0] = f;
+    // the tree with folded leaves, when asked for: a flattener and a thread of its own
+    out.beam_nodes.clear();
+    Flattener fl_beam{out};
+    fl_beam.face_box = boxes.get();
+    fl_beam.order = b.order.data();
+    fl_beam.dst = &out.beam_nodes;
+    fl_beam.merge_faces = 8;  // what a leaf reference can hold
+    std::thread beam_thread;
+    if (want_beam_tree) {
+        out.beam_nodes.reserve(n_faces / 4 + 1);
+        beam_thread = std::thread([&] { fl_beam.tree(root.get()); });
     }
+    fl.tree(root.get());
 
     stage("fast tree");
     // The quantised copy of the tree.  The grid spans the union of all child boxes (they carry the padding), widened a little.
-    {
+    // (Not for a scene the pixel-beam tree was asked for: its material only emits, so no ray is ever scattered and the walk
+    // that reads these nodes never runs.)
+    out.q_nodes.clear();
+    out.q4_nodes.clear();
+    out.q4_depth = 1;
+    for (int a = 0; a < 3; a++) { out.grid_lo[a] = 0; out.grid_step[a] = 1; }
+    if (!want_beam_tree) {
         float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         bool any = false;
         for (const FastNode& f : out.fast_nodes)
@@ -474,7 +516,7 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
 
     stage("quantised nodes");
     // Two levels per node.  Built without recursion (a work list of (binary node, slot to patch)): trees of scans are deep.
-    {
+    if (!want_beam_tree) {
         out.q4_nodes.clear();
         out.q4_nodes.reserve(out.q_nodes.size() / 2 + 1);
         struct Todo { int32_t bin; int32_t parent; int slot; int32_t depth; };
@@ -550,6 +592,7 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out) {
     out.fast_depth = std::max(fl.fast_depth, 1);
     prim_thread.join();
     ref_thread.join();
+    if (beam_thread.joinable()) beam_thread.join();
     stage("joined the other two");
     out.info.n_faces = n_faces;
     out.info.n_nodes = out.ref_nodes.size();

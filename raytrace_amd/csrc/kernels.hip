@@ -717,7 +717,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
             if (lx < pass.dx && ly < pass.local_rows && row < pass.dy) {
                 const DMesh& m = sc.meshes[sc.nodes[0].index];
                 if (beam_setup(cam, pass.dx, pass.dy, m, lx, pass.dy - 1 - row, st)) {
-                    found = beam_fill(sc.fast_nodes + m.fast_off, st, dyn_lds + p * 2 * ls.cap, ls.cap, beam_cand + p * kBeamCands * 3, vc.overflow RT_BEAM_STEPS);
+                    found = beam_fill(sc.fast_nodes + m.beam_off, st, dyn_lds + p * 2 * ls.cap, ls.cap, beam_cand + p * kBeamCands * 3, vc.overflow RT_BEAM_STEPS);
                     if (st[12] != kFastEmpty) found |= 0x100;  // the list goes on: this pixel's rounds walk it in instalments
                 }
             }
@@ -844,10 +844,10 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                     if (walking) {
 #ifdef RT_VISIT_STATS
                         uint32_t again = 0;
-                        if (p == pb) px_state[15] = beam_fill(sc.fast_nodes + m.fast_off, px_state, dyn_lds + pb * 2 * ls.cap, ls.cap, px_cand, vc.overflow, again);
+                        if (p == pb) px_state[15] = beam_fill(sc.fast_nodes + m.beam_off, px_state, dyn_lds + pb * 2 * ls.cap, ls.cap, px_cand, vc.overflow, again);
                         RT_STAT(7, 1);  // instalments walked inside rounds
 #else
-                        if (p == pb) px_state[15] = beam_fill(sc.fast_nodes + m.fast_off, px_state, dyn_lds + pb * 2 * ls.cap, ls.cap, px_cand, vc.overflow);
+                        if (p == pb) px_state[15] = beam_fill(sc.fast_nodes + m.beam_off, px_state, dyn_lds + pb * 2 * ls.cap, ls.cap, px_cand, vc.overflow);
 #endif
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();

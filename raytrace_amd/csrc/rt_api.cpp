@@ -398,9 +398,15 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         for (int v = 0; v < 3; v++) { face_uv[i * 6 + v * 2] = d->faces[i].v[v][3]; face_uv[i * 6 + v * 2 + 1] = d->faces[i].v[v][4]; }
     sc->bvh_info.resize(d->n_meshes);
     int32_t stack_pairs = 2;
+    // What the pixel-beam kernel renders: one untransformed mesh whose material only emits (the camera decides per frame)
+    bool beam_scene = d->n_nodes == 1 && d->n_meshes == 1 && nodes[0].kind == RT_SHAPE_MESH && std::getenv("RT_NO_BEAM") == nullptr;
+    if (beam_scene) {
+        const int k = d->materials[nodes[0].material].kind;
+        beam_scene = k == RT_MAT_EMITTER || k == RT_MAT_DEBUG_UV || k == RT_MAT_DEBUG_NORMAL;
+    }
     for (uint64_t i = 0; i < d->n_meshes; i++) {
         MeshBvh b;
-        build_mesh_bvh(d->faces + d->meshes[i].first_face, d->meshes[i].n_faces, b);
+        build_mesh_bvh(d->faces + d->meshes[i].first_face, d->meshes[i].n_faces, b, beam_scene);
         DMesh& m = meshes[i];
         m.ref_off = (int64_t)ref_nodes.size();
         m.fast_off = (int64_t)fast_nodes.size();
@@ -424,6 +430,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         take(fast_nodes, b.fast_nodes);
         take(q_nodes, b.q_nodes);
         take(q4_nodes, b.q4_nodes);
+        m.beam_off = m.fast_off;
+        if (!b.beam_nodes.empty()) {  // behind the mesh's own nodes; its child references are relative to beam_off
+            m.beam_off = (int64_t)fast_nodes.size();
+            fast_nodes.insert(fast_nodes.end(), b.beam_nodes.begin(), b.beam_nodes.end());
+        }
         walk_cap = std::max(walk_cap, std::max(b.fast_depth + 1, 3 * b.q4_depth + 1));
         deepest_fast = std::max(deepest_fast, (int32_t)b.fast_depth);
         take(prim_pos, b.prim_pos);

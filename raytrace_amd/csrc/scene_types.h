@@ -65,6 +65,7 @@ struct DMesh {
     int32_t pad2;
     float grid_lo[3], grid_step[3];  // the grid of this mesh's QNodes (mesh frame)
     int64_t q4_off;    // first Q4Node
+    int64_t beam_off;  // first FastNode of the tree the pixel-beam walk uses (leaves folded to eight faces); = fast_off when there is none
 };
 
 struct NodePair32 {
