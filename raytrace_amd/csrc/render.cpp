@@ -601,9 +601,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
     // Pixel beams (one tree walk per pixel instead of one per 64 samples, see dev_bvh.h): parallel rays through one mesh.
     const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC && !getenv("RT_NO_BEAM");
-    // a lane walks for each pixel of an item: eight pixels keep eight lanes busy in that phase; a device's share of a frame
-    // split over four or more devices is better off with four (the last items of a short launch weigh more)
-    if (beam) item_rays = tiles_total * 64 >= 3000000 ? 2048 : 1024;
+    const bool item_rays_fixed = getenv("RT_ITEM_RAYS") != nullptr;
     if (const char* e = getenv("RT_ITEM_RAYS")) item_rays = std::max(1, atoi(e));
     for (int s0 = s_first; s0 < s_end;) {
         // a pass covers all tiles for a run of samples when that fits, else a run of tiles for one sample
@@ -647,7 +645,18 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 pass.log2_s = log2_s;
                 // pixels per item: about item_rays rays (512: smaller items shorten the tail of a launch, 2-3 % on an eighth of a 4K frame), at least what the wave traces at a time, at most the tile
                 int block = 64 >> log2_s;
-                while (block < 64 && (int64_t)block * s_count < item_rays) block <<= 1;
+                int64_t want_rays = item_rays;
+                if (beam && !item_rays_fixed) {
+                    // Pixel beams: a lane walks the tree for each pixel of an item, so more pixels keep more lanes busy in that
+                    // phase (eight at most); against that an item should not run much longer than 4096 rays and a resident wave
+                    // should get some 120 items, or the last items of the launch leave the chip waiting.  Measured on the 4K scan
+                    // and on a half, a quarter and an eighth of it (1024 samples: 4 / 4 / 4 / 2 pixels; 256 samples: 8 and 4).
+                    int64_t px = std::min<int64_t>(std::min<int64_t>(8, std::max<int64_t>(1, tiles_total * 64 / 491520)), std::max<int64_t>(1, 4096 / s_count));
+                    px = std::max<int64_t>(px, std::min<int64_t>(8, 1024 / std::max(1, s_count)));
+                    while (px & (px - 1)) px &= px - 1;  // down to a power of two
+                    want_rays = px * s_count;
+                }
+                while (block < 64 && (int64_t)block * s_count < want_rays) block <<= 1;
                 if (beam && log2_s == 6) block = std::min(block, beam_pixels_max());
                 pass.block_px = block;
             }
