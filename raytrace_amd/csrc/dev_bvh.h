@@ -872,8 +872,16 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
 // mesh_collide_fast passes, the fat ray's passes; float32 rounding of the bundle's own numbers is covered by a margin of
 // 2^-21 of the mesh radius on top of the boxes' padding.
 
-constexpr int kBeamPixels = 8;      // pixels of a work item at most (one lane walks each)
-constexpr int kBeamCands = 48;      // faces listed per pixel at a time; a longer list is produced in instalments
+#ifndef RT_BEAM_PIXELS
+#define RT_BEAM_PIXELS 8
+#endif
+constexpr int kBeamPixels = RT_BEAM_PIXELS;      // pixels of a work item at most (one lane walks each)
+#ifndef RT_BEAM_CANDS
+#define RT_BEAM_CANDS 64
+#endif
+// leaves listed per pixel at a time; a longer list is produced in instalments.  The lists of a wave's pixels live in LDS, which
+// caps the occupancy: measured on the 4K scan, pixels x leaves = 8 x 48: 59.5 Grays/s, 8 x 64: 63.0, 8 x 80: 54.0, 4 x 96: 63.9, 4 x 128: 63.6, 4 x 192: 54.2
+constexpr int kBeamCands = RT_BEAM_CANDS;
 constexpr int kBeamStateDwords = 32;
 
 // What a lane's walk keeps between instalments, in LDS (dwords): 0-2 a, 3-5 b (slab distance of a min plane p is
