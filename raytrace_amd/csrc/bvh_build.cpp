@@ -288,7 +288,10 @@ struct Flattener {
         for (uint32_t i = 1; i < count; i++) b = unite(b, face_box[order[first + i]]);
         return b;
     }
-    static int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+    // A leaf: the complement of (first face << leaf_bits | faces - 1).  3 bits (up to 8 faces) in the trees every walk reads;
+    // the pixel beams' tree uses 4 (up to 16 faces; first face below 2^27).
+    int leaf_bits = 3;
+    int32_t leaf_ref(uint32_t first, uint32_t count) const { return ~(int32_t)((first << leaf_bits) | (count - 1)); }
 
     std::vector<FastNode>* dst = nullptr;  // the tree fast() writes: out.fast_nodes or out.beam_nodes
     uint32_t merge_faces = 0;              // > 0: a subtree of at most that many faces becomes one leaf
@@ -302,7 +305,7 @@ struct Flattener {
     };
 
     int32_t chunk(uint32_t first, uint32_t count) {
-        if (count <= 8) return leaf_ref(first, count);
+        if (count <= (1u << leaf_bits)) return leaf_ref(first, count);
         DepthScope scope(*this);
         const int32_t me = (int32_t)(*dst).size();
         (*dst).emplace_back();
@@ -460,7 +463,8 @@ void build_mesh_bvh(const rt_face* faces, uint64_t n_faces, MeshBvh& out, bool w
     fl_beam.face_box = boxes.get();
     fl_beam.order = b.order.data();
     fl_beam.dst = &out.beam_nodes;
-    fl_beam.merge_faces = 8;  // what a leaf reference can hold
+    fl_beam.leaf_bits = RT_BEAM_LEAF_BITS;
+    fl_beam.merge_faces = 1u << RT_BEAM_LEAF_BITS;  // what a leaf reference of that tree can hold
     std::thread beam_thread;
     if (want_beam_tree) {
         out.beam_nodes.reserve(n_faces / 4 + 1);

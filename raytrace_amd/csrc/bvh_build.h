@@ -6,6 +6,12 @@
 
 #include "../../include/rt_hip.h"
 
+// Bits of a leaf reference that hold (faces - 1) in the pixel beams' own tree (DMesh::beam_off); 3 in every other tree.
+// Leaves of up to 16 faces (4 bits) were measured and changed nothing on the 4K scan (135.5 against 135.2 ms per frame).
+#ifndef RT_BEAM_LEAF_BITS
+#define RT_BEAM_LEAF_BITS 3
+#endif
+
 namespace rt {
 
 // Node of the reference-order tree, depth-first pre-order: the left child of an

@@ -883,6 +883,8 @@ constexpr int kBeamPixels = RT_BEAM_PIXELS;      // pixels of a work item at mos
 // caps the occupancy: measured on the 4K scan, pixels x leaves = 8 x 48: 59.5 Grays/s, 8 x 64: 63.0, 8 x 80: 54.0, 4 x 96: 63.9, 4 x 128: 63.6, 4 x 192: 54.2
 constexpr int kBeamCands = RT_BEAM_CANDS;
 constexpr int kBeamStateDwords = 32;
+constexpr int kBeamLeafFaces = 1 << RT_BEAM_LEAF_BITS;             // faces a leaf of the beams' tree holds at most
+constexpr uint32_t kBeamLeafMask = (1u << kBeamLeafFaces) - 1u;  // one bit per face of such a leaf
 
 // What a lane's walk keeps between instalments, in LDS (dwords): 0-2 a, 3-5 b (slab distance of a min plane p is
 // p * i + a, of a max plane p * i + b), 6-8 i = 1 / direction, 9 t_lo (where the rays start, in the bundle's frame),
@@ -1025,7 +1027,7 @@ RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int 
             if (count == kBeamCands) break;  // the list is full: the next instalment resumes at this leaf
             cand[3 * count] = cur;
             cand[3 * count + 1] = __float_as_int(cur_tn);
-            cand[3 * count + 2] = 0xff >> (7 - (int)((uint32_t)~cur & 7u));  // every face of the leaf, until beam_cull_item has looked
+            cand[3 * count + 2] = (int32_t)(kBeamLeafMask >> (kBeamLeafFaces - 1 - (int)((uint32_t)~cur & (uint32_t)(kBeamLeafFaces - 1))));  // every face of the leaf, until beam_cull_item has looked
             count++;
             pop();
         }
@@ -1048,7 +1050,7 @@ RT_DEV void beam_suffix_min(int32_t* cand, int n) {
     }
 }
 
-// The whole wave thins the complete lists of an item's pixels out: eight lanes per listed leaf, one per face, each
+// The whole wave thins the complete lists of an item's pixels out: kBeamLeafFaces lanes per listed leaf, one per face, each
 // testing its face against the bundle of the leaf's pixel (beam_rejects_face); the faces that survive become the
 // leaf's mask.  All the faces of eight leaves are fetched at once, so an item pays a few memory round trips here
 // instead of one per face in every round.  prefix: 9 dwords of LDS.  Must be entered by all 64 lanes.
@@ -1069,8 +1071,8 @@ RT_DEV void beam_cull_item(const Tri32* tri32, float radius, int32_t* beam_state
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int total = __builtin_amdgcn_readfirstlane(prefix[kBeamPixels]);
-    for (int base = 0; base < total; base += 8) {
-        const int s = base + (lane >> 3), q = lane & 7;
+    for (int base = 0; base < total; base += 64 / kBeamLeafFaces) {
+        const int s = base + lane / kBeamLeafFaces, q = lane & (kBeamLeafFaces - 1);
         bool keep = false;
         int32_t* entry = beam_cand;
         if (s < total) {
@@ -1080,16 +1082,16 @@ RT_DEV void beam_cull_item(const Tri32* tri32, float radius, int32_t* beam_state
                 if (s >= prefix[k]) j = k;
             entry = beam_cand + (j * kBeamCands + (s - prefix[j])) * 3;
             const uint32_t code = (uint32_t)~entry[0];
-            if (q <= (int)(code & 7u)) {
+            if (q <= (int)(code & (uint32_t)(kBeamLeafFaces - 1))) {
                 const int32_t* st = beam_state + j * kBeamStateDwords;
                 const float dx = __int_as_float(st[22]), dy = __int_as_float(st[23]), dz = __int_as_float(st[24]);
                 const float err_d = kErr * sqrtf(dx * dx + dy * dy + dz * dz);
-                keep = !beam_rejects_face(tri32[(int32_t)(code >> 3) + q], __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]),
+                keep = !beam_rejects_face(tri32[(int32_t)(code >> RT_BEAM_LEAF_BITS) + q], __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]),
                                           __int_as_float(st[19]), __int_as_float(st[20]), __int_as_float(st[21]), dx, dy, dz, err_d * radius, err_d);
             }
         }
         const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
-        if (s < total && q == 0) entry[2] = (int32_t)((kept >> (lane & 56)) & 0xffull);
+        if (s < total && q == 0) entry[2] = (int32_t)((kept >> (lane & (64 - kBeamLeafFaces))) & (unsigned long long)kBeamLeafMask);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1120,7 +1122,7 @@ RT_DEV void beam_test(const DScene& sc, const DMesh& m, const Ray& r, const Fast
             if (minima) break;
             continue;
         }
-        const int32_t first = (int32_t)((uint32_t)~__builtin_amdgcn_readfirstlane(cand[3 * c]) >> 3);
+        const int32_t first = (int32_t)((uint32_t)~__builtin_amdgcn_readfirstlane(cand[3 * c]) >> RT_BEAM_LEAF_BITS);
         RT_STAT(2, 1);
         for (; mask != 0; mask &= mask - 1) {
             const int32_t face = first + (__builtin_ffs((int)mask) - 1);
