@@ -597,7 +597,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     int pass_samples = 1024;
     if (const char* e = getenv("RT_PASS_SAMPLES")) pass_samples = std::max(1, atoi(e));
     int lanes_override = -1;   // RT_LOG2_LANES / RT_ITEM_RAYS: tuning knobs of the primary launch
-    int64_t item_rays = 512;
+    int64_t item_rays = 256;   // measured 64 / 128 / 256 / 512, Grays/s: scan-lit 5.54 / 5.53 / 5.44 / 5.20, material 7.31 / 7.30 / 7.28 / 7.18, teapot 5.43 / 5.50 / 5.54 / 5.56, charuco orbit 610 / 670 / 681 / 662 frames/s
     if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
     // Pixel beams (one tree walk per pixel instead of one per 64 samples, see dev_bvh.h): parallel rays through one mesh.
     const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC && !getenv("RT_NO_BEAM");
@@ -643,7 +643,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
             pass.sample_count = s_count;
             {
                 pass.log2_s = log2_s;
-                // pixels per item: about item_rays rays (512: smaller items shorten the tail of a launch, 2-3 % on an eighth of a 4K frame), at least what the wave traces at a time, at most the tile
+                // pixels per item: about item_rays rays (smaller items shorten the tail of a launch), at least what the wave traces at a time, at most the tile
                 int block = 64 >> log2_s;
                 int64_t want_rays = item_rays;
                 if (beam && !item_rays_fixed) {
