@@ -63,6 +63,12 @@ extern __shared__ int32_t dyn_lds[];
 #ifndef RT_FAST_WAVES
 #define RT_FAST_WAVES 3
 #endif
+#ifndef RT_SHAPES_SHADE_WAVES
+#define RT_SHAPES_SHADE_WAVES 2  // the primary kernel of scenes without any mesh, with Material.Resolve
+#endif
+#ifndef RT_SHAPES_WAVES
+#define RT_SHAPES_WAVES 4  // ... and without (every material only emits): charuco orbit 696 frames/s at 3 waves, 735 at 4, 578 at 2
+#endif
 
 // ---- scene level intersection ---------------------------------------------------------------
 
@@ -84,7 +90,7 @@ RT_DEV bool mesh_node_collide(const DScene& sc, int index, const Ray& r, double 
 // renormalised, so t is preserved), the innermost shape is intersected, and the hit point and
 // normal come back through the forward transforms.
 // PACKET (fast mode): the lanes of the wave trace neighbouring rays and walk a mesh together (mesh_collide_packet).
-template <int MODE, bool PACKET = false>
+template <int MODE, bool PACKET = false, bool NO_MESH = false>
 // uv_now = false: the texture coordinates of an untransformed sphere (atan2 / acos, some hundred instructions) are left
 // at 0; the caller computes them with sphere_uv() from the normal if the hit wins and its material reads them.
 RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in, double tmin, double tmax, Col& c, int& prim, int& leaf,
@@ -111,7 +117,7 @@ RT_DEV bool shape_collide(const DScene& sc, int kind, int index, const Ray& r_in
         case RT_SHAPE_QUAD: hit = quad_collide(sc.quads[index], r, tmin, tmax, c); break;
         case RT_SHAPE_CYLINDER: hit = cylinder_collide(sc.cylinders[index], r, tmin, tmax, c); break;
         case RT_SHAPE_TRIANGLE: hit = tri_collide(sc.tris[index], r, tmin, tmax, c); break;
-        case RT_SHAPE_MESH: hit = mesh_node_collide<MODE, PACKET>(sc, index, r, tmin, tmax, c, prim, leaf, cnt, ls); break;
+        case RT_SHAPE_MESH: if (!NO_MESH) hit = mesh_node_collide<MODE, PACKET>(sc, index, r, tmin, tmax, c, prim, leaf, cnt, ls); break;  // NO_MESH: the host has checked that there is none
         default: break;
     }
     if (hit) {
@@ -233,7 +239,7 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
     auto visit = [&](int i, const DNode nd) {
         Col c;
         int prim, leaf;
-        const bool got = shape_collide<MODE, PACKET>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, leaf, cnt, ls, false);
+        const bool got = shape_collide<MODE, PACKET, NO_MESH>(sc, nd.kind, nd.index, r, tmin, min_dist, c, prim, leaf, cnt, ls, false);
         if (got && c.t < min_dist) {
             min_dist = c.t;
             h.c = c;
@@ -683,7 +689,7 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 // "pixel beams" in dev_bvh.h.  Dynamic LDS then holds the walking lanes' stacks (lane j: 2 * cap dwords at j * 2 * cap),
 // the running sums, and at pass.beam_offset the lists (kBeamPixels x kBeamCands triples), the walks' states and 16 dwords
 // for beam_cull_item.
-template <int MODE, bool MESH_ONLY, bool SHADE, bool BEAM>
+template <int MODE, bool MESH_ONLY, bool SHADE, bool BEAM, bool NO_MESH>
 RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, double* __restrict__ film, long long v,
                          uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, uint32_t& rot,
                          VisitCounts& vc) {
@@ -819,7 +825,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                 ps.depth_n = rng.n;
                 if (!BEAM) {
                     V3 em;
-                    const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST>(sc, r, mk(1, 1, 1), h, em, ls, vc);
+                    const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST, NO_MESH>(sc, r, mk(1, 1, 1), h, em, ls, vc);
                     if (what == 1) { acc_lds[0] += em.x; acc_lds[64] += em.y; acc_lds[128] += em.z; }
                     want = what == 2;
                     missed = what == 0;
@@ -922,8 +928,8 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
 // queues exhausted.
 // SHADE = false: the host has checked that every material only emits, so no hit ever needs Material.Resolve and
 // its code (and registers) is left out.
-template <int MODE, bool MESH_ONLY, bool SHADE, bool BEAM = false>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY ? (SHADE ? RT_PACKET_SHADE_WAVES : RT_PACKET_WAVES) : (SHADE ? RT_FAST_SHADE_WAVES : RT_FAST_WAVES)) : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
+template <int MODE, bool MESH_ONLY, bool SHADE, bool BEAM = false, bool NO_MESH = false>
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY ? (SHADE ? RT_PACKET_SHADE_WAVES : RT_PACKET_WAVES) : (NO_MESH ? (SHADE ? RT_SHAPES_SHADE_WAVES : RT_SHAPES_WAVES) : (SHADE ? RT_FAST_SHADE_WAVES : RT_FAST_WAVES))) : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
     // The camera and the queue descriptors are read through pointers where they are used: as by-value arguments
     // their ~100 dwords would sit in SGPRs for the whole kernel and push other scalars out into VGPR lanes.
     const DCamera& cam = *camp;
@@ -970,7 +976,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         if (v < 0) break;
         const long long t_start = pass.cost ? clock64() : 0;
         sub = __shfl(sub, 0, 64);
-        primary_item<MODE, MESH_ONLY, SHADE, BEAM>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
+        primary_item<MODE, MESH_ONLY, SHADE, BEAM, NO_MESH>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
                                              reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left, n_culled, rot, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
@@ -1706,6 +1712,9 @@ void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, 
         constexpr int M = decltype(mode_tag)::value;
         if (M == RT_MODE_FAST && beam) go(k_primary<RT_MODE_FAST, true, false, true>);
         else if (mesh_only) { if (shade) go(k_primary<M, true, true>); else go(k_primary<M, true, false>); }
+        else if (M == RT_MODE_FAST && sc.n_meshes == 0) {  // no tree to walk: the walk's code and registers are left out
+            if (shade) go(k_primary<RT_MODE_FAST, false, true, false, true>); else go(k_primary<RT_MODE_FAST, false, false, false, true>);
+        }
         else           { if (shade) go(k_primary<M, false, true>); else go(k_primary<M, false, false>); }
     };
     if (mode == RT_MODE_REFERENCE) pick(std::integral_constant<int, RT_MODE_REFERENCE>{});
