@@ -49,7 +49,7 @@ extern __shared__ int32_t dyn_lds[];
 #define RT_TRACE_WAVES 3  // k_trace, mesh-only scenes
 #endif
 #ifndef RT_TRACE_SHAPES_WAVES
-#define RT_TRACE_SHAPES_WAVES 2  // k_trace for scenes without any mesh: 256 VGPRs, nothing spilled (at 3 waves 168 VGPRs + 328 B of scratch per lane: a third slower on the sphere scenes; with a mesh in the scene the walk's latency wants the third wave)
+#define RT_TRACE_SHAPES_WAVES 3  // k_trace for scenes without any mesh: 168 VGPRs and 136 B of scratch per lane; 2 waves (201 VGPRs, nothing spilled) measured 4 % slower on cornell and 9 % on material, 4 waves 15 % and 6 % slower than 3
 #endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 3  // k_shade
