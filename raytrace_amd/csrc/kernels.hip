@@ -54,6 +54,12 @@ extern __shared__ int32_t dyn_lds[];
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 3  // k_shade
 #endif
+#ifndef RT_DIRECT_SHAPES_WAVES
+#define RT_DIRECT_SHAPES_WAVES 4  // k_direct of scenes without any mesh: 99 VGPRs without the walk (167 with it)
+#endif
+#ifndef RT_DIRECT_SHAPES_RUNS_WAVES
+#define RT_DIRECT_SHAPES_RUNS_WAVES 3  // ... with runs of lights per thread: 88 B of spills instead of 320; the 257-light charuco frame 54.9 -> 46.1 ms (2 waves: 57.4, 4 waves: 45.9)
+#endif
 #ifndef RT_DIRECT_WAVES
 #define RT_DIRECT_WAVES 3  // k_direct
 #endif
@@ -326,7 +332,8 @@ RT_DEV bool scene_closest(const DScene& sc, const Ray& r, double tmin, double tm
 // Occlusion loop of ComputeDirectLighting (material_lambertian.go:34-45): any node other than
 // the one whose shape was hit.  Reference mode runs the full closest-hit Collide per node as
 // the reference does; fast mode stops at the first face hit.
-template <int MODE>
+// NO_MESH: the host has checked that no node holds a mesh; the tree walk's code and registers are left out.
+template <int MODE, bool NO_MESH = false>
 RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self_node, LdsStack ls, VisitCounts& cnt) {
     const DNode self = sc.nodes[self_node];
     V3 inv = mk(0, 0, 0);
@@ -355,7 +362,7 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
             if (nd.kind == self.kind && nd.index == self.index) continue;
             Col c;
             int prim, leaf;
-            if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, leaf, cnt, ls, false)) return true;
+            if (shape_collide<MODE, false, NO_MESH>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, leaf, cnt, ls, false)) return true;
         }
         return false;
     }
@@ -367,7 +374,7 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
         const DNode nd = sc.nodes[i];
         if (nd.kind == self.kind && nd.index == self.index) continue;
         if (MODE == RT_MODE_FAST && !q32.ok && nd.kind != RT_SHAPE_MESH && !node_box_reachable(sc.node_box + (size_t)i * 6, r, inv, kEps, dist)) continue;
-        if (MODE == RT_MODE_FAST && nd.kind == RT_SHAPE_MESH) {
+        if (MODE == RT_MODE_FAST && !NO_MESH && nd.kind == RT_SHAPE_MESH) {
             double t, u, v;
             int p;
             // (Two other walks were tried here and lost.  The four-wide one of k_walk: a third slower, also on the points of
@@ -379,7 +386,7 @@ RT_DEV bool scene_occluded(const DScene& sc, const Ray& r, double dist, int self
         }
         Col c;
         int prim, leaf;
-        if (shape_collide<MODE>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, leaf, cnt, ls, false)) return true;
+        if (shape_collide<MODE, false, NO_MESH>(sc, nd.kind, nd.index, r, kEps, dist, c, prim, leaf, cnt, ls, false)) return true;
     }
     return false;
 }
@@ -1481,8 +1488,8 @@ __global__ void __launch_bounds__(kSortBlock, WAVES) k_shade(DScene sc, PassDesc
 #ifndef RT_DIRECT_RUNS_WAVES
 #define RT_DIRECT_RUNS_WAVES 3  // 2 waves (no spills) measured 107 ms on the 257-light frame, 3 waves (320 B of spills) 95 ms
 #endif
-template <int MODE, bool RUNS>
-__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (RUNS ? RT_DIRECT_RUNS_WAVES : RT_DIRECT_WAVES) : 2) k_direct(DScene sc, Queues q, StripeCounts cnt, int per_thread_arg, uint32_t n_runs, uint32_t group, double* __restrict__ film) {
+template <int MODE, bool RUNS, bool NO_MESH = false>
+__global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (NO_MESH ? (RUNS ? RT_DIRECT_SHAPES_RUNS_WAVES : RT_DIRECT_SHAPES_WAVES) : (RUNS ? RT_DIRECT_RUNS_WAVES : RT_DIRECT_WAVES)) : 2) k_direct(DScene sc, Queues q, StripeCounts cnt, int per_thread_arg, uint32_t n_runs, uint32_t group, double* __restrict__ film) {
     const int per_thread = RUNS ? per_thread_arg : 1;
     // blockIdx.y = stripe of the surface-point queue.  blockIdx.x = `group` chunks of 64 points for the first run of lights, the
     // same chunks for the second run, ..., then the next group of chunks.  group = 8 (many lights): workgroups are dealt
@@ -1519,7 +1526,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (RUNS ? RT
             else wo = mk(q.surfs.wo[0][i], q.surfs.wo[1][i], q.surfs.wo[2][i]);
             const V3 adds = light_contribution(m, L, n, wo, alb, q.surfs.inside[i], dir, sh.d);
             if (MODE == RT_MODE_FAST && adds.x == 0 && adds.y == 0 && adds.z == 0) continue;
-            if (!scene_occluded<MODE>(sc, sh, dist, node, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc)) contrib = contrib + adds;
+            if (!scene_occluded<MODE, NO_MESH>(sc, sh, dist, node, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs}, vc)) contrib = contrib + adds;
         } while (RUNS && ++light < light1);
         RT_WFLUSH(vc);
     }
@@ -1771,7 +1778,11 @@ void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf
         if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_REFERENCE, true>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, runs, group, film);
         else hipLaunchKernelGGL((k_direct<RT_MODE_REFERENCE, false>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, runs, group, film);
     } else {
-        if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_FAST, true>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, runs, group, film);
+        if (sc.n_meshes == 0) {  // no tree to walk
+            if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_FAST, true, true>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, runs, group, film);
+            else hipLaunchKernelGGL((k_direct<RT_MODE_FAST, false, true>), grid, dim3(kTraceBlock), 0, s, sc, q, n_surf, per_thread, runs, group, film);
+        }
+        else if (per_thread > 1) hipLaunchKernelGGL((k_direct<RT_MODE_FAST, true>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, runs, group, film);
         else hipLaunchKernelGGL((k_direct<RT_MODE_FAST, false>), grid, dim3(kTraceBlock), stack_bytes(sc, mode), s, sc, q, n_surf, per_thread, runs, group, film);
     }
 }
