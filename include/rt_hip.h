@@ -370,8 +370,10 @@ int rt_render_film(rt_scene* scene, const rt_camera_desc* camera, const rt_rende
                    double* film_dev, rt_stats* stats);
 
 /* rt_render_film without a single device allocation, for callers that cannot
- * allocate: code under HIP graph capture, tight frame loops, harnesses that
- * forbid hipMalloc.  No counterpart in the reference.  Same arguments, same
+ * allocate: tight frame loops, harnesses that forbid hipMalloc, hosts that
+ * prepare everything up front.  (The call still synchronises its stream and
+ * copies counters to the host, so it cannot itself run inside a stream
+ * capture.)  No counterpart in the reference.  Same arguments, same
  * film, same statistics as rt_render_film; the counters, the camera, the queue
  * descriptors and the tile schedule live in a static array in device memory
  * (2.1 MB, held by every GPU the library runs on until the process ends)

@@ -19,6 +19,10 @@ extern std::atomic<bool> g_initialized;
 // The devices rt_init selected, in the caller's order.  The same ordinal may appear more than once: every entry gets a
 // replica and a stream of its own (a one-GPU machine can rehearse the multi-device path that way).
 extern std::vector<int> g_devices;
+// Whether films may travel from device `from` to device `to` with a direct device-to-device copy: the same device, or a pair
+// for which rt_init found and enabled peer access.  Otherwise they go through pinned host memory.  RT_NO_PEER=1 (read by
+// rt_init) forbids every direct copy, which lets a machine with one GPU run the staged route.
+bool peer_copy_allowed(int from, int to);
 
 #define HIP_TRY(expr)                                                                                             \
     do {                                                                                                          \
@@ -70,8 +74,10 @@ struct Replica {
     hipStream_t stream = nullptr;  // created for replicas 1..n-1; replica 0 renders on the caller's stream
     double* film = nullptr;        // replicas 1..n-1: this device's radiance sums of the frame being rendered
     size_t film_doubles = 0;
-    double* inbox = nullptr;       // on the FIRST device: where this replica's film lands before it is added (sample split)
+    double* inbox = nullptr;       // on the FIRST device: where this replica's share of the film lands before it is added
     size_t inbox_doubles = 0;
+    double* staging = nullptr;     // pinned host memory: the way to the inbox when the two devices have no direct path
+    size_t staging_doubles = 0;
     hipEvent_t done = nullptr;     // recorded on `stream` when this replica's share of a frame is finished
 };
 

@@ -68,6 +68,7 @@ void launch_trace(const DScene& sc, const PassDesc& pass, const Queues& q, int i
 void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf, int mode, double* film, hipStream_t s);
 void launch_resolve(const double* film, int32_t dx, int32_t dy, int32_t spp, uint8_t* rgba, hipStream_t s);
 void launch_film_add(double* dst, const double* src, size_t n, hipStream_t s);  // dst[i] += src[i], both on the current device
+void launch_film_add_bands(double* dst, const double* src, int dx, int dy, int first, int step, hipStream_t s);  // the same on the rows of every step-th 16-row band from `first`
 
 // Static scratch of rt_render_film_noalloc: a file-scope __device__ array in kernels.hip.  Layout (offsets in bytes, each
 // a multiple of 256): Counters, DCamera, Queues, then kStaticTiles tile costs and kStaticTiles tile numbers.

@@ -1892,6 +1892,25 @@ void launch_film_add(double* dst, const double* src, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_film_add, dim3(blocks_for(n)), dim3(kBlock), 0, s, dst, src, n);
 }
 
+// dst += src on the rows of the 16-row bands first, first + step, first + 2 step, ... of a film of dy rows of row_doubles
+// numbers: one device's share of a frame divided by rows, added into the frame on the first device.
+__global__ void __launch_bounds__(kBlock) k_film_add_bands(double* __restrict__ dst, const double* __restrict__ src, size_t row_doubles, int dy, int first,
+                                                           int step, size_t n) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const size_t local_row = i / row_doubles, col = i - local_row * row_doubles;
+    const size_t row = ((local_row >> 4) * (size_t)step + (size_t)first) * 16 + (local_row & 15);
+    if (row >= (size_t)dy) return;  // the last band of the frame may be a partial one
+    dst[row * row_doubles + col] += src[row * row_doubles + col];
+}
+
+void launch_film_add_bands(double* dst, const double* src, int dx, int dy, int first, int step, hipStream_t s) {
+    const int bands = (dy + 15) / 16;
+    if (first >= bands || step <= 0) return;
+    const size_t mine = (size_t)((bands - first + step - 1) / step) * 16, row_doubles = (size_t)dx * 3, n = mine * row_doubles;
+    hipLaunchKernelGGL(k_film_add_bands, dim3(blocks_for(n)), dim3(kBlock), 0, s, dst, src, row_doubles, dy, first, step, n);
+}
+
 // ---- static scratch ------------------------------------------------------------------------------
 // Device memory the library owns without ever allocating it: every GPU that loads this code object holds its own
 // copy of the array, at its own address, until the process ends.  rt_render_film_noalloc keeps its counters, camera,

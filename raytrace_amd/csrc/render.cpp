@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -438,6 +439,8 @@ WorkBuffers* static_work_for(int device, int64_t tiles_total) {
                                      std::to_string(kStaticTiles) + " (4096 x 4096 pixels)");
         return nullptr;
     }
+    static std::mutex table_mutex;  // two threads may make their first call on a device at the same time
+    std::lock_guard<std::mutex> lock(table_mutex);
     WorkBuffers& w = table[device];
     if (!w.is_static) {
         void* base = nullptr;
@@ -521,7 +524,9 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     Queues& q = w.queues;
     hipStream_t stream = reinterpret_cast<hipStream_t>(o->stream);
     if (static_work) HIP_TRY(hipMemcpyAsync(w.d_queues, &w.queues, sizeof(Queues), hipMemcpyHostToDevice, stream));
-    sc->cancel.store(false);
+    // rt_cancel's flag belongs to the API call (cleared where rt_render / rt_render_film / rt_render_frames begin): it is only
+    // read here -- before every launch and once more when the last launch has ended -- so a frame that is a single launch,
+    // and the other devices' shares of a frame, see it too.
     HIP_TRY(hipMemcpyAsync(w.d_camera, &cam, sizeof(DCamera), hipMemcpyHostToDevice, stream));  // pageable source: staged before the call returns
 
     const auto t_start = std::chrono::steady_clock::now();
@@ -788,6 +793,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
         s0 += s_count;
     }
     if (int rc = read_counters()) return rc;
+    if (sc->cancel.load()) return fail(RT_ERR_CANCELLED, "render cancelled");  // the film holds a frame nobody waits for any more
 #ifdef RT_VISIT_STATS
     {
         unsigned long long ps[16];
@@ -846,7 +852,8 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
 // pixels of one image (render.go:297-331).  Here every device of rt_init holds a replica of the scene and renders a
 // share of the frame into a film in its own memory, driven by a host thread of its own:
 //   rows     band b of 16 rows (the reference's tile height) goes to device b % n; afterwards every device copies its
-//            bands into the first device's film over its own link (disjoint rows: the frame is exact);
+//            bands to the first device over its own link, where they are added to the caller's film (disjoint rows:
+//            the frame is exact, and a film that already holds earlier passes keeps them);
 //   samples  device i renders the i-th run of sample indices of EVERY pixel (the random streams are keyed by pixel
 //            and sample index, so the samples are the ones a single device would draw); the films are copied to the
 //            first device and added there.  For frames with few pixels and many samples per pixel.
@@ -899,12 +906,12 @@ int render_all_devices(rt_scene* sc, const rt_camera_desc* camera, const rt_rend
         split = (s_total / n >= 256 && (int64_t)o->dx * o->dy <= (int64_t)2048 * 2048) ? RT_SPLIT_SAMPLES : RT_SPLIT_ROWS;
     if (split == RT_SPLIT_SAMPLES && s_total < n) split = RT_SPLIT_ROWS;
     Replica& first = *sc->replicas[0];
+    // every other device's share lands in an inbox of its own on the first device and is ADDED to the caller's film there:
+    // rt_render_film adds to the film it is given (progressive passes), whichever way the frame is divided
     for (int i = 1; i < n; i++)
-        if (int rc = ensure_peer_buffers(first, *sc->replicas[(size_t)i], film_doubles, split == RT_SPLIT_SAMPLES)) return rc;
+        if (int rc = ensure_peer_buffers(first, *sc->replicas[(size_t)i], film_doubles, true)) return rc;
     HIP_TRY(hipSetDevice(first.device));
     hipStream_t stream0 = reinterpret_cast<hipStream_t>(o->stream);
-    // what the caller queued before this call (zeroing the film) must have happened before a peer writes into the film
-    HIP_TRY(hipEventRecord(first.done, stream0));
 
     const auto t_start = std::chrono::steady_clock::now();
     std::vector<Share> shares((size_t)n);
@@ -938,19 +945,43 @@ int render_all_devices(rt_scene* sc, const rt_camera_desc* camera, const rt_rend
         sh.rc = render_into_film(sc, rep, camera, &mine, target, &sh.stats);
         if (sh.rc != RT_OK) { sh.error = last_error_text(); return; }
         if (i == 0) return;
-        // render_into_film has synchronised rep.stream: the share is complete.  Send it to the first device.
-        e = hipStreamWaitEvent(rep.stream, first.done, 0);
-        if (e != hipSuccess) return fail_here(e, "hipStreamWaitEvent");
+        // render_into_film has synchronised rep.stream: the share is complete.  Send it to its inbox on the first device:
+        // the bands of this device (rows split) or the whole film (samples split).
+        const bool direct = peer_copy_allowed(rep.device, first.device);
+        const size_t row_doubles = (size_t)o->dx * 3;
+        auto send = [&](size_t off, size_t count) -> hipError_t {
+            if (direct) return hipMemcpyPeerAsync(rep.inbox + off, first.device, rep.film + off, rep.device, count * sizeof(double), rep.stream);
+            // no direct path between the two devices: through pinned host memory (device -> host here, host -> inbox below)
+            return hipMemcpyAsync(rep.staging + off, rep.film + off, count * sizeof(double), hipMemcpyDeviceToHost, rep.stream);
+        };
+        if (!direct && rep.staging_doubles < film_doubles) {
+            if (rep.staging) (void)hipHostFree(rep.staging);
+            rep.staging = nullptr;
+            rep.staging_doubles = 0;
+            e = hipHostMalloc(reinterpret_cast<void**>(&rep.staging), film_doubles * sizeof(double), hipHostMallocPortable);
+            if (e != hipSuccess) return fail_here(e, "hipHostMalloc (staging copy between devices without peer access)");
+            rep.staging_doubles = film_doubles;
+        }
         if (split == RT_SPLIT_ROWS) {
-            const size_t row_doubles = (size_t)o->dx * 3;
             for (int band = i; band * 16 < o->dy && e == hipSuccess; band += n) {
                 const size_t rows = (size_t)std::min(16, o->dy - band * 16), off = (size_t)band * 16 * row_doubles;
-                e = hipMemcpyPeerAsync(film + off, first.device, rep.film + off, rep.device, rows * row_doubles * sizeof(double), rep.stream);
+                e = send(off, rows * row_doubles);
             }
         } else {
-            e = hipMemcpyPeerAsync(rep.inbox, first.device, rep.film, rep.device, film_doubles * sizeof(double), rep.stream);
+            e = send(0, film_doubles);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(rep.stream);
+        if (e == hipSuccess && !direct) {
+            e = hipSetDevice(first.device);
+            if (split == RT_SPLIT_ROWS) {
+                for (int band = i; band * 16 < o->dy && e == hipSuccess; band += n) {
+                    const size_t rows = (size_t)std::min(16, o->dy - band * 16), off = (size_t)band * 16 * row_doubles;
+                    e = hipMemcpy(rep.inbox + off, rep.staging + off, rows * row_doubles * sizeof(double), hipMemcpyHostToDevice);
+                }
+            } else if (e == hipSuccess) {
+                e = hipMemcpy(rep.inbox, rep.staging, film_doubles * sizeof(double), hipMemcpyHostToDevice);
+            }
+        }
         if (e != hipSuccess) return fail_here(e, "copy to the first device");
     };
     std::vector<std::thread> threads;
@@ -960,10 +991,11 @@ int render_all_devices(rt_scene* sc, const rt_camera_desc* camera, const rt_rend
     HIP_TRY(hipSetDevice(first.device));
     for (const Share& sh : shares)
         if (sh.rc != RT_OK) return fail(sh.rc, sh.error);
-    if (split == RT_SPLIT_SAMPLES) {
-        for (int i = 1; i < n; i++) launch_film_add(film, sc->replicas[(size_t)i]->inbox, film_doubles, stream0);
-        HIP_TRY(hipGetLastError());
+    for (int i = 1; i < n; i++) {
+        if (split == RT_SPLIT_SAMPLES) launch_film_add(film, sc->replicas[(size_t)i]->inbox, film_doubles, stream0);
+        else launch_film_add_bands(film, sc->replicas[(size_t)i]->inbox, o->dx, o->dy, i, n, stream0);
     }
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream0));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));

@@ -26,6 +26,8 @@ namespace rt {
 thread_local std::string tl_error;
 std::atomic<bool> g_initialized{false};
 std::vector<int> g_devices;
+static bool g_peer_ok[64][64];  // [from][to], by device ordinal; written by rt_init only
+bool peer_copy_allowed(int from, int to) { return from >= 0 && to >= 0 && from < 64 && to < 64 && g_peer_ok[from][to]; }
 std::atomic<uint64_t> g_scene_serial{0};
 
 int fail(int code, const std::string& msg) {
@@ -154,6 +156,7 @@ rt_scene::~rt_scene() {
         (void)hipSetDevice(rep->device);
         rt::destroy_work(rep->work);
         if (rep->film) (void)hipFree(rep->film);
+        if (rep->staging) (void)hipHostFree(rep->staging);
         if (rep->stream) (void)hipStreamDestroy(rep->stream);
         if (rep->done) (void)hipEventDestroy(rep->done);
         rep.reset();  // frees the scene arrays with this replica's device current
@@ -173,8 +176,9 @@ int rt_init(const int* gpu_ids, int n) {
     if (gpu_ids && n > 0) devices.assign(gpu_ids, gpu_ids + n);
     else devices.push_back(0);
     if (devices.size() > 64) return fail(RT_ERR_INVALID, "more than 64 devices");
+    const bool no_peer = std::getenv("RT_NO_PEER") != nullptr, verbose = std::getenv("RT_DEBUG") != nullptr;
     for (int dev : devices) {
-        if (dev < 0 || dev >= count) return fail(RT_ERR_INVALID, "device ordinal out of range");
+        if (dev < 0 || dev >= count || dev >= 64) return fail(RT_ERR_INVALID, "device ordinal out of range");
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
@@ -186,12 +190,20 @@ int rt_init(const int* gpu_ids, int n) {
         // entry point itself only reads it (the look-up may load the code object, which allocates)
         void* scratch_ptr = nullptr;
         HIP_TRY(static_scratch(dev, &scratch_ptr));
-        for (int other : devices) {  // films travel between the devices: direct access where the links allow it
-            int can = 0;
-            if (other == dev || hipDeviceCanAccessPeer(&can, dev, other) != hipSuccess || !can) continue;
-            const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(RT_ERR_DEVICE, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
-            (void)hipGetLastError();
+        for (int other : devices) {  // films travel between the devices: direct copies where the links allow them, through the host where not
+            bool ok = !no_peer;
+            if (ok && other != dev) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, dev, other) != hipSuccess || !can) {
+                    ok = false;
+                } else {
+                    const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                }
+                (void)hipGetLastError();
+            }
+            g_peer_ok[dev][other] = ok;
+            if (verbose && other != dev) fprintf(stderr, "[rt] rt_init: device %d -> %d: %s\n", dev, other, ok ? "direct copies" : "no peer access, films are staged through pinned host memory");
         }
     }
     HIP_TRY(hipSetDevice(devices[0]));
@@ -674,6 +686,7 @@ void rt_cancel(rt_scene* scene) {
 
 int rt_render_film(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opts* opts, double* film_dev, rt_stats* stats) {
     if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
+    if (scene) scene->cancel.store(false);
     return render_all_devices(scene, camera, opts, film_dev, stats);
 }
 
@@ -691,6 +704,7 @@ int rt_render_film_noalloc(rt_scene* scene, const rt_camera_desc* camera, const 
     Replica& rep = *scene->replicas[0];
     WorkBuffers* w = static_work_for(rep.device, tiles);
     if (!w) return RT_ERR_UNSUPPORTED;  // message set by static_work_for
+    scene->cancel.store(false);
     return render_into_film(scene, rep, camera, opts, film_dev, stats, w);
 }
 
@@ -738,6 +752,7 @@ int rt_render(rt_scene* scene, const rt_camera_desc* camera, const rt_render_opt
     if (!g_initialized) return fail(RT_ERR_NOT_INITIALIZED, "rt_init has not been called");
     Replica& first = *scene->replicas[0];
     HIP_TRY(hipSetDevice(first.device));
+    scene->cancel.store(false);  // a cancel that came after an earlier call had ended is not meant for this one
     double* film = nullptr;
     uint8_t *rgba = nullptr, *rgba_host = nullptr;
     if (int rc = scene_film(scene, first, opts->dx, opts->dy, &film, &rgba, &rgba_host)) return rc;
@@ -837,7 +852,13 @@ int rt_render_frames(rt_scene* scene, const rt_camera_desc* cameras, int32_t n_f
     std::string message;
     hipError_t e = hipSuccess;
     const size_t n = (size_t)opts->dx * opts->dy * 3;
+    scene->cancel.store(false);  // the flag belongs to this call: render_into_film reads it, nobody resets it until the call ends
     for (int i = 0; i < n_frames && rc == RT_OK && e == hipSuccess; i++) {
+        if (scene->cancel.load()) {  // between frames: a loop of one-launch frames has no other place to stop
+            rc = RT_ERR_CANCELLED;
+            message = "render cancelled";
+            break;
+        }
         const int s = i % depth;
         {  // the set's staging buffer is free once the frame that used it last has been handed over
             std::unique_lock<std::mutex> lock(mu);

@@ -424,10 +424,11 @@ struct Builder {
         });
         std::vector<uint8_t> raw = base64(pix);
         int64_t w = x1 - x0, h = y1 - y0, n = int64_t(raw.size());
-        if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || stride < 4 * w || n < stride * (h - 1) + 4 * w)
+        // every product below stays far inside int64: w, h <= 65536 and stride <= n (the decoded bytes: at most the text's length)
+        if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || stride < 4 * w || stride > n || (h - 1) > (n - 4 * w) / stride)
             bad("TextureImage.Image: " + std::to_string(n) + " bytes of pixels for " + std::to_string(w) + "x" + std::to_string(h) +
                 ", stride " + std::to_string(stride));
-        bool wide = stride >= 8 * w && n >= stride * (h - 1) + 8 * w;  // 16 bits per channel, big-endian (image.RGBA64)
+        bool wide = stride >= 8 * w && n >= 8 * w && (h - 1) <= (n - 8 * w) / stride;  // 16 bits per channel, big-endian (image.RGBA64)
         std::vector<uint8_t> px(size_t(w) * size_t(h) * (wide ? 8 : 4));
         for (int64_t y = 0; y < h; y++) {
             const uint8_t* row = raw.data() + y * stride;
@@ -446,7 +447,19 @@ struct Builder {
         images.push_back(im);  // the pointers are set once nothing is appended any more
         return int(images.size()) - 1;
     }
+    // Textures and shapes nest (TextureCheckerboard.Odd / Even, TransformedShape.Shape): a text may not drive the reader's
+    // own recursion deeper than this (encoding/json gives up at 10000 levels; rt_scene_create takes 4 for shapes anyway).
+    static constexpr int kMaxNesting = 64;
+    int nesting = 0;
+    struct Nest {
+        int& n;
+        explicit Nest(int& depth) : n(depth) {
+            if (++n > kMaxNesting) { --n; bad("scene JSON: values nested deeper than " + std::to_string(kMaxNesting)); }
+        }
+        ~Nest() { --n; }
+    };
     int texture(Typed t) {
+        Nest guard(nesting);
         rt_texture x{};
         Cur c = t.data;
         if (t.type == "TextureUniform") {
@@ -578,6 +591,7 @@ struct Builder {
         });
     }
     void shape(Typed t, int32_t& kind, int32_t& index) {
+        Nest guard(nesting);
         Cur c = t.data;
         if (t.type == "Sphere") {
             rt_sphere s{};
@@ -824,6 +838,8 @@ extern "C" int rt_scene_create_from_json(const char* text, size_t len, rt_scene*
         return rt::fail(e.code, "scene JSON: " + e.msg);
     } catch (const std::bad_alloc&) {
         return rt::fail(RT_ERR_NOMEM, "scene JSON: out of host memory");
+    } catch (const std::exception& e) {  // nothing may cross the C boundary (length_error of a container, system_error, ...)
+        return rt::fail(RT_ERR_INVALID, std::string("scene JSON: ") + e.what());
     }
     for (size_t i = 0; i < b.images.size(); i++) b.images[i].pixels = b.pixels[i].data();
     rt_scene_desc d{};

@@ -105,3 +105,53 @@ def test_tiny_and_degenerate_meshes(monkeypatch):
         assert np.array_equal(beam.Image, packet.Image)
         assert _stats(beam.Stats) == _stats(packet.Stats)
         assert 0 < beam.Stats.RaysLeftScene < beam.Stats.TotalRays
+
+
+def _film(dev, lib, sc, band=(0, 1), spp=None):
+    import ctypes as C
+    import torch
+    from raytrace_amd import _lib
+    o = sc.RenderOptions
+    film = torch.zeros((o.Dy, o.Dx, 3), dtype=torch.float64, device="cuda")
+    cd = phys.camera_desc(sc.Camera[0])
+    ro = phys.render_opts(o, abi.MODE_FAST, band[0], band[1], torch.cuda.current_stream().cuda_stream, 0, spp or o.RaysPerPixel)
+    st = abi.Stats()
+    _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
+    torch.cuda.synchronize()
+    out = film.cpu().numpy()
+    del film
+    return out, (st.total_rays, st.rays_left_scene, st.rays_exceeded_depth, st.shadow_rays)
+
+
+def test_beam_kernel_at_the_bench_size_equals_the_packet_walk_and_the_oracle(ob, monkeypatch):
+    """The kernel the bench times, at the bench's size: 1 310 720 faces, 3840 x 2160, 64 samples (one launch of the beam kernel
+    with 64-leaf lists, four-pixel items and instalment walks on the folded-leaf tree).  Its film -- float64 radiance sums,
+    before any quantisation -- must equal the packet walk's number for number, a two-band split of it must add up to the same
+    film, and on every 16th tile row and column it must equal the oracle's sums."""
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    sc = scenes.scan(level=8, dx=3840, dy=2160, spp=64, tex_size=1024)
+    with phys.DeviceScene(sc) as dev:
+        monkeypatch.setenv("RT_NO_PIXEL_CULL", "1")  # as in the bench's timed steps: every tile traced
+        beam, beam_stats = _film(dev, lib, sc)
+        monkeypatch.setenv("RT_NO_BEAM", "1")
+        packet, packet_stats = _film(dev, lib, sc)
+        monkeypatch.delenv("RT_NO_BEAM")
+        assert beam_stats == packet_stats and beam_stats[0] == 3840 * 2160 * 64
+        assert np.array_equal(beam, packet)
+        del packet
+        monkeypatch.delenv("RT_NO_PIXEL_CULL")
+        culled, culled_stats = _film(dev, lib, sc)  # the library's default: tiles and pixels outside the outline settled by count
+        assert culled_stats == beam_stats and np.array_equal(culled, beam)
+        del culled
+        halves = [_film(dev, lib, sc, (r, 2)) for r in (0, 1)]
+        assert np.array_equal(halves[0][0] + halves[1][0], beam)  # disjoint bands: one of the two addends is zero everywhere
+        assert tuple(a + b for a, b in zip(halves[0][1], halves[1][1])) == beam_stats
+        del halves
+    with ob.OracleScene(sc) as orc:
+        img, st, _, ref = orc.render(sc.Camera[0], sc.RenderOptions, n_threads=16, tile_step=16, want_film=True)
+    mask = img[..., 3] == 255  # the pixels the oracle rendered
+    assert mask.sum() >= 100 * 256
+    err = np.abs(beam[mask] - ref[mask]) / np.maximum(np.abs(ref[mask]), 1.0)
+    assert err.max() < 1e-12, err.max()
+    assert (ref[mask] > 0).any(axis=1).mean() > 0.2  # the sample is not all background

@@ -92,3 +92,47 @@ def test_frame_loop_and_beam_kernel_on_two_replicas(two_devices):
     for a, b in zip(st_one, st_two):
         assert (a.TotalRays, a.RaysLeftScene) == (b.TotalRays, b.RaysLeftScene)
     assert len({one[i].tobytes() for i in range(4)}) == 4
+
+
+def _film_passes(sc, passes, split, lib=None):
+    """rt_render_film called once per (sample_begin, sample_count) of `passes` into ONE film: progressive rendering."""
+    import ctypes as C
+    import torch
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    o = sc.RenderOptions
+    film = torch.zeros((o.Dy, o.Dx, 3), dtype=torch.float64, device="cuda")
+    cd = phys.camera_desc(sc.Camera[0])
+    total = 0
+    with phys.DeviceScene(sc) as dev:
+        for s0, cnt in passes:
+            ro = phys.render_opts(o, abi.MODE_FAST, 0, 1, torch.cuda.current_stream().cuda_stream, s0, cnt)
+            ro.device_split = split
+            st = abi.Stats()
+            _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
+            total += st.total_rays
+    torch.cuda.synchronize()
+    return film.cpu().numpy(), total
+
+
+@pytest.mark.parametrize("no_peer", [False, True])
+def test_progressive_passes_into_one_film_accumulate_on_every_device(two_devices, monkeypatch, no_peer):
+    """rt_render_film ADDS to the film it is given: two passes of half the samples each, divided by rows or by samples among
+    two replicas, must leave the sums one device leaves -- also in the bands the other device renders, and also when the
+    films travel through pinned host memory because the devices have no direct path (RT_NO_PEER=1)."""
+    from raytrace_amd import _lib
+    lib, devices = two_devices
+    sc = scenes.scan(level=5, dx=512, dy=392, spp=128, tex_size=256)
+    one, n_one = _film_passes(sc, [(0, 128)], abi.SPLIT_AUTO)
+    if no_peer:
+        monkeypatch.setenv("RT_NO_PEER", "1")
+    _lib.init(lib, devices)
+    monkeypatch.delenv("RT_NO_PEER", raising=False)
+    for split in (abi.SPLIT_ROWS, abi.SPLIT_SAMPLES):
+        two, n_two = _film_passes(sc, [(0, 64), (64, 64)], split)
+        assert n_two == n_one
+        err = np.abs(two - one) / np.maximum(np.abs(one), 1.0)
+        assert err.max() < 1e-12, (split, err.max())  # the same samples; only the order of the additions differs
+        for band in (0, 1):  # rows of both devices hold both passes
+            rows = np.arange(392)[(np.arange(392) // 16) % 2 == band]
+            assert one[rows].sum() > 0 and abs(two[rows].sum() / one[rows].sum() - 1) < 1e-12

@@ -100,6 +100,56 @@ def test_cancel_returns_cancelled_and_scene_stays_usable():
         assert art.Stats.TotalRays >= 64 * 36
 
 
+def test_cancel_stops_a_loop_of_one_launch_frames_and_a_single_launch_frame():
+    """Emit-only frames are ONE launch each: the flag is looked at between the frames of rt_render_frames and once a
+    frame's launch has ended, and a cancel that arrived after an earlier call had ended is not held against the next."""
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    sc = scenes.scan(level=6, dx=1920, dy=1080, spp=1024, tex_size=256)
+    n_frames = 1500  # several seconds of work if not cancelled
+    with phys.DeviceScene(sc) as dev:
+        cams = (abi.CameraDesc * n_frames)(*[phys.camera_desc(sc.Camera[0])] * n_frames)
+        ro = phys.render_opts(phys.RenderOptions(0, 1024, 10, 320, 180), abi.MODE_FAST)
+        imgs = np.zeros((n_frames, 180, 320, 4), dtype=np.uint8)
+        stats = (abi.Stats * n_frames)()
+        result = {}
+
+        def run():
+            result["rc"] = lib.rt_render_frames(dev.handle, cams, n_frames, C.byref(ro), imgs.ctypes.data_as(C.POINTER(C.c_uint8)), 320 * 4,
+                                                320 * 180 * 4, stats, 1)
+            result["msg"] = lib.rt_last_error()
+
+        lib.rt_cancel(dev.handle)  # stale: no call is running
+        th = threading.Thread(target=run)
+        t0 = time.time()
+        th.start()
+        time.sleep(0.4)
+        lib.rt_cancel(dev.handle)
+        th.join(60)
+        assert not th.is_alive()
+        assert result["rc"] == abi.RT_ERR_CANCELLED and b"cancel" in result["msg"], result
+        done = sum(1 for s in stats if s.total_rays > 0)
+        assert 0 < done < n_frames, done  # the stale cancel did not stop frame 0, the live one stopped the loop
+        assert time.time() - t0 < 20
+        assert imgs[0].any()  # frames handed over before the cancel stay valid
+        # a single frame that is one launch: cancelled while the launch runs, reported when it has ended
+        big = phys.render_opts(phys.RenderOptions(0, 1024, 10, 1920, 1080), abi.MODE_FAST)
+        img = np.zeros((1080, 1920, 4), dtype=np.uint8)
+        cd = phys.camera_desc(sc.Camera[0])
+
+        def one():
+            result["rc1"] = lib.rt_render(dev.handle, C.byref(cd), C.byref(big), img.ctypes.data_as(C.POINTER(C.c_uint8)), 1920 * 4, None)
+
+        th = threading.Thread(target=one)
+        th.start()
+        time.sleep(0.01)
+        lib.rt_cancel(dev.handle)
+        th.join(60)
+        assert result["rc1"] in (abi.RT_ERR_CANCELLED, abi.RT_OK)  # RT_OK only if the frame had ended within the 10 ms
+        art = dev.render(sc.Camera[0], phys.RenderOptions(0, 1, 2, 64, 36), abi.MODE_FAST)
+        assert art.Stats.TotalRays >= 64 * 36
+
+
 @pytest.mark.parametrize("name,spp", [("cornell", 2048), ("material", 4096)])
 def test_converged_image_rmse_against_oracle(ob, name, spp):
     """Images converged at thousands of samples per pixel, GPU (fast mode) against the CPU oracle with a DIFFERENT

@@ -274,3 +274,45 @@ def test_bvh_build_reports_the_size_it_needs():
     inner = tree[tree["right"] >= 0]
     assert (inner["count"] == 0).all() and (tree[tree["right"] < 0]["count"] > 0).all()
     assert lib.rt_bvh_build(faces.ctypes.data, 0, nodes.ctypes.data, 1, leaf.ctypes.data, C.byref(count)) != abi.RT_OK
+
+
+def _create_from_text(text):
+    """rt_scene_create_from_json on a text that must be refused while it is read (no GPU is touched before the reader is done)."""
+    import ctypes as C
+    from raytrace_amd import _lib
+    lib = _lib.host_library()
+    handle = C.c_void_p()
+    raw = text.encode()
+    rc = lib.rt_scene_create_from_json(raw, len(raw), C.byref(handle), None)
+    return rc, (lib.rt_last_error() or b"").decode(), handle
+
+
+def _scene_with_texture(texture_json):
+    return ('{"Camera":[],"Light":[],"Node":[{"Name":"n","Shape":{"Type":"Sphere","Data":{"Center":{"X":0,"Y":0,"Z":0},"Radius":1,"UVMap":0}},'
+            '"Material":{"Type":"Emitter","Data":{"Type":"Emitter","Texture":' + texture_json + '}}}],"RenderOptions":{"Seed":0,"RaysPerPixel":1,"MaxRayDepth":1,"Dx":8,"Dy":8}}')
+
+
+def test_an_image_stride_that_would_wrap_the_bounds_check_is_refused():
+    """Stride comes straight from the text: 2^62 x (h - 1) wraps to 0 in 64 bits and would pass a check written as a product."""
+    import base64
+    pix = base64.b64encode(bytes(4 * 2 * 5)).decode()
+    for stride in (2 ** 62, 2 ** 61 + 8, 9 * 10 ** 18):
+        image = '{"Pix":"%s","Stride":%d,"Rect":{"Min":{"X":0,"Y":0},"Max":{"X":2,"Y":5}}}' % (pix, stride)
+        tex = '{"Type":"TextureImage","Data":{"Image":%s,"FilePath":"","Interp":"nearest","WrapMode":"repeat"}}' % image
+        rc, msg, handle = _create_from_text(_scene_with_texture(tex))
+        assert rc == abi.RT_ERR_INVALID and "stride" in msg and not handle.value, (stride, rc, msg)
+
+
+def test_textures_and_shapes_nested_beyond_the_limit_are_refused_not_followed():
+    depth = 20000  # enough frames of the reader's recursion to run a thread's stack out, were it followed
+    flat = '{"Type":"TextureUniform","Data":{"Type":"TextureUniform","Color":{"X":1,"Y":1,"Z":1}}}'
+    head = '{"Type":"TextureCheckerboard","Data":{"Type":"TextureCheckerboard","Frequency":1,"Even":' + flat + ',"Odd":'
+    rc, msg, handle = _create_from_text(_scene_with_texture(head * depth + flat + "}}" * depth))
+    assert rc == abi.RT_ERR_INVALID and "nested deeper" in msg and not handle.value, (rc, msg[:200])
+    sphere = '{"Type":"Sphere","Data":{"Center":{"X":0,"Y":0,"Z":0},"Radius":1,"UVMap":0}}'
+    head = '{"Type":"TransformedShape","Data":{"Shape":'
+    tail = ',"Transform":{"Translate":{"X":0,"Y":0,"Z":0},"Rotate":{"M":[[1,0,0],[0,1,0],[0,0,1]]},"Scale":{"X":1,"Y":1,"Z":1}}}}'
+    text = ('{"Camera":[],"Light":[],"Node":[{"Name":"n","Shape":' + head * depth + sphere + tail * depth + ',"Material":{"Type":"DebugNormal","Data":{}}}],'
+            '"RenderOptions":{"Seed":0,"RaysPerPixel":1,"MaxRayDepth":1,"Dx":8,"Dy":8}}')
+    rc, msg, handle = _create_from_text(text)
+    assert rc == abi.RT_ERR_INVALID and "nested deeper" in msg and not handle.value, (rc, msg[:200])

@@ -51,6 +51,33 @@ def test_no_alloc_render_matches_rt_render_film_twice():
               _film(lib, lib.rt_render_film, dev, sc, 200, 150, 2, abi.MODE_REFERENCE, (1, 3)))
 
 
+def test_no_alloc_render_leaves_the_free_device_memory_as_it_was():
+    """The entry point's whole contract: on a handle that has rendered once, a call (pilot pass, occupancy map and schedule
+    included: the camera changes) allocates and frees nothing on the device."""
+    import torch
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    sc = scenes.scan(level=5, dx=512, dy=384, spp=34, tex_size=256)
+    o = phys.RenderOptions(0, 34, 10, 512, 384)
+    film = torch.zeros((384, 512, 3), dtype=torch.float64, device="cuda")
+    ro = phys.render_opts(o, abi.MODE_FAST, 0, 1, torch.cuda.current_stream().cuda_stream)
+    with phys.DeviceScene(sc) as dev:
+        other = phys.OrthographicCamera(LookFrom=(70.0e9, 60.0e9, 100.0e9), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0), FOVHeight=250.0,
+                                        FOVWidth=250.0 * 512 / 384)
+        cams = [phys.camera_desc(sc.Camera[0]), phys.camera_desc(other)]
+        _lib.check(lib.rt_render_film_noalloc(dev.handle, C.byref(cams[0]), C.byref(ro), C.c_void_p(film.data_ptr()), None), lib)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        lowest = free_before
+        for cd in (cams[1], cams[0], cams[1]):
+            st = abi.Stats()
+            _lib.check(lib.rt_render_film_noalloc(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
+            lowest = min(lowest, torch.cuda.mem_get_info()[0])
+            assert st.total_rays == 512 * 384 * 34
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before and lowest == free_before
+
+
 def test_no_alloc_render_of_a_second_scene_does_not_reuse_the_first_schedule():
     from raytrace_amd import _lib
     lib = _lib.load()

@@ -13,9 +13,12 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (source_hash: the device sources these figures belong to; run this on the tree that was profiled)
+
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/counters.json"
-rays = float(sys.argv[3]) if len(sys.argv) > 3 else 2123366400.0
+rays = float(sys.argv[3]) if len(sys.argv) > 3 else 8493465600.0
 TIMED = int(os.environ.get("TIMED_LAUNCHES", "4"))  # the last launches of the run are bench.py's timed steps
 KERNEL = os.environ.get("PMC_KERNEL", "k_primary")
 
@@ -37,6 +40,7 @@ f, w = per_launch("fetch", "FETCH_SIZE"), per_launch("write", "WRITE_SIZE")
 act, thr = per_launch("sq2", "SQ_ACTIVE_INST_VALU"), per_launch("sq2", "SQ_THREAD_CYCLES_VALU")
 insts, gui = per_launch("sq1", "SQ_INSTS_VALU"), per_launch("grbm", "GRBM_GUI_ACTIVE")
 res = {
+    "csrc_sha16": bench.source_hash(),
     "kernel": KERNEL, "timed_launches_averaged": TIMED, "rays_per_launch": rays,
     "k_primary_hbm_bytes_per_launch": (2.0 * f + w) * 1024 if f is not None and w is not None else None,
     "fetch_size_kib_per_launch_raw": f, "write_size_kib_per_launch_raw": w,
