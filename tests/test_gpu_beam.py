@@ -116,7 +116,12 @@ def _film(dev, lib, sc, band=(0, 1), spp=None):
     cd = phys.camera_desc(sc.Camera[0])
     ro = phys.render_opts(o, abi.MODE_FAST, band[0], band[1], torch.cuda.current_stream().cuda_stream, 0, spp or o.RaysPerPixel)
     st = abi.Stats()
-    _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
+    # Twice: the first frame of a (camera, frame, share, culling) combination on a handle spends its first two samples on a
+    # pilot pass that records what the tiles cost, so its sums are added up as 2 + 62 samples; the frames after it, from the
+    # schedule, as one pass of 64.  The same samples either way -- but "number for number" wants the same order of additions.
+    for _ in range(2):
+        film.zero_()
+        _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
     torch.cuda.synchronize()
     out = film.cpu().numpy()
     del film
