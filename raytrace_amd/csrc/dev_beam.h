@@ -1,0 +1,204 @@
+// The pixel-beam kernel's own tables and per-ray tests.
+//
+// Every ray of an orthographic camera has the camera's direction d (camera_orthographic.go:44), so the part of
+// Face.Collide (shape_mesh.go:95-124) that does not depend on the ray's origin is the same for every ray of a frame:
+//   edge1 = p1 - p0, edge2 = p2 - p0, h = d x edge2, a = edge1 . h, the test -1e-8 < a < 1e-8, f = 1 / a.
+// k_beam_prepare computes these once per face and direction, with the operations and their order exactly as in mt_core
+// (dev_shapes.h) -- the library is compiled without floating-point contraction -- so what a ray computes from them,
+//   s = o - p0, u = f (s . h), q = s x edge1, v = f (d . q), t = f (edge2 . q),
+// are the reference's numbers bit for bit.  The conservative float32 pre-test is prepared the same way: with
+// U = s . (d x e2) and V = s . (e1 x d) the face can be rejected when U < -eu, V < -ev or U + V > |a| + eu + ev + ea (signs
+// mirrored for a < 0; margins as in tri32_rejects), which per ray is a subtraction, two dot products and three compares.
+#pragma once
+
+#include "dev_bvh.h"
+#include "dev_shade.h"
+
+namespace rt {
+
+RT_DEV BeamFace32 load_face32_scalar(const BeamFace32* t, int32_t index) {
+    const RT_CONST_AS i32x4* p = (const RT_CONST_AS i32x4*)(t + index);
+    union {
+        i32x4 v[3];
+        BeamFace32 f;
+    } u;
+    u.v[0] = p[0]; u.v[1] = p[1]; u.v[2] = p[2];
+    return u.f;
+}
+
+// One ray (float32 origin in the bundle's frame) against one prepared face: true = the float64 test cannot accept it.
+RT_DEV bool face32_rejects(const BeamFace32& t, float ox, float oy, float oz) {
+#pragma clang fp contract(fast)
+    const float sx = ox - t.p0[0], sy = oy - t.p0[1], sz = oz - t.p0[2];
+    const float us = sx * t.h[0] + sy * t.h[1] + sz * t.h[2];
+    const float vs = sx * t.g[0] + sy * t.g[1] + sz * t.g[2];
+    return us < t.neg_eu || vs < t.neg_ev || us + vs > t.lim;
+}
+
+// The same for a whole bundle: origins within (ex, ey, ez) of (ox, oy, oz) per axis.  U and V are linear in the origin,
+// so over the footprint they stay within dU = sum e_k |h_k| and dV = sum e_k |g_k| of their values at the centre.
+RT_DEV bool face32_rejects_bundle(const BeamFace32& t, float ox, float oy, float oz, float ex, float ey, float ez) {
+#pragma clang fp contract(fast)
+    const float sx = ox - t.p0[0], sy = oy - t.p0[1], sz = oz - t.p0[2];
+    const float us = sx * t.h[0] + sy * t.h[1] + sz * t.h[2];
+    const float vs = sx * t.g[0] + sy * t.g[1] + sz * t.g[2];
+    const float slack = 1.0f + 1.0f / 65536.0f;  // the bounds themselves are rounded
+    const float dU = (ex * fabsf(t.h[0]) + ey * fabsf(t.h[1]) + ez * fabsf(t.h[2])) * slack;
+    const float dV = (ex * fabsf(t.g[0]) + ey * fabsf(t.g[1]) + ez * fabsf(t.g[2])) * slack;
+    return us + dU < t.neg_eu || vs + dV < t.neg_ev || (us - dU) + (vs - dV) > t.lim;
+}
+
+// beam_cull_item (dev_bvh.h) on the prepared faces: kBeamLeafFaces lanes per listed leaf, one per face, each testing its
+// face against the bundle of the leaf's pixel; the survivors become the leaf's mask.  Must be entered by all 64 lanes.
+RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32_t* beam_cand, int32_t* prefix, int n_px, int lane) {
+    int len = 0;
+    if (lane < n_px) {
+        const int32_t v = beam_state[lane * kBeamStateDwords + 15];
+        len = (v & 0x100) ? 0 : (v & 0xff);  // a list that goes on is walked in instalments inside the rounds, unthinned
+    }
+    int incl = len;
+#pragma unroll
+    for (int off = 1; off < kBeamPixels; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane < kBeamPixels) prefix[lane + 1] = incl;
+    if (lane == 0) prefix[0] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int total = __builtin_amdgcn_readfirstlane(prefix[kBeamPixels]);
+    for (int base = 0; base < total; base += 64 / kBeamLeafFaces) {
+        const int s = base + lane / kBeamLeafFaces, q = lane & (kBeamLeafFaces - 1);
+        bool keep = false;
+        int32_t* entry = beam_cand;
+        if (s < total) {
+            int j = 0;
+#pragma unroll
+            for (int k = 1; k < kBeamPixels; k++)
+                if (s >= prefix[k]) j = k;
+            entry = beam_cand + (j * kBeamCands + (s - prefix[j])) * 3;
+            const uint32_t code = (uint32_t)~entry[0];
+            if (q <= (int)(code & (uint32_t)(kBeamLeafFaces - 1))) {
+                const int32_t* st = beam_state + j * kBeamStateDwords;
+                keep = !face32_rejects_bundle(faces[(int32_t)(code >> RT_BEAM_LEAF_BITS) + q], __int_as_float(st[16]), __int_as_float(st[17]),
+                                              __int_as_float(st[18]), __int_as_float(st[19]), __int_as_float(st[20]), __int_as_float(st[21]));
+            }
+        }
+        const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
+        if (s < total && q == 0) entry[2] = (int32_t)((kept >> (lane & (64 - kBeamLeafFaces))) & (unsigned long long)kBeamLeafMask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The faces of n listed leaves (those their masks name) against this lane's ray: beam_test (dev_bvh.h) on the prepared
+// tables.  o: the ray's float64 origin; (fx, fy, fz): the same in the bundle's float32 frame; d: the camera's direction
+// (the same for every lane).  Must be entered by the lanes of a wave together.
+RT_DEV void beam_test_prepared(const BeamTables& bt, V3 o, V3 d, float fx, float fy, float fz, double T, const int32_t* cand, int n, bool minima,
+                               double tmin, bool sound, BeamHit& bh) {
+    for (int c = 0; c < n; c++) {
+        uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane(cand[3 * c + 2]);
+        if (mask == 0) continue;  // no face of this leaf can be hit by any ray of the bundle
+        const float tb = __int_as_float(__builtin_amdgcn_readfirstlane(cand[3 * c + 1]));
+        if (__builtin_amdgcn_ballot_w64(sound && tb <= bh.tmax32) == 0) {  // the leaf begins beyond every lane's hit
+            if (minima) break;
+            continue;
+        }
+        const int32_t first = (int32_t)((uint32_t)~__builtin_amdgcn_readfirstlane(cand[3 * c]) >> RT_BEAM_LEAF_BITS);
+        RT_STAT(2, 1);
+        for (; mask != 0; mask &= mask - 1) {
+            const int32_t face = first + (__builtin_ffs((int)mask) - 1);
+            const BeamFace32 t32 = load_face32_scalar(bt.f32, face);
+            const bool maybe = sound && tb <= bh.tmax32 && !face32_rejects(t32, fx, fy, fz);
+            RT_STAT(3, 1);
+            if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+            RT_STAT(4, 1);
+            const RT_CONST_AS double* p = (const RT_CONST_AS double*)(bt.f64 + face);
+            const double f = p[12];
+            // a face the reference rejects whatever the ray (shape_mesh.go:107-109): f is NaN, all bits of its exponent set
+            if (((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(__double_as_longlong(f) >> 32)) & 0x7ff00000u) == 0x7ff00000u) continue;
+            if (maybe) {
+                // shape_mesh.go:110-124 with edge1, edge2, h, f as prepared; e = 1e-8
+                const double e = 1e-8;
+                const V3 s = o - mk(p[0], p[1], p[2]);
+                const double u = f * dot(s, mk(p[9], p[10], p[11]));
+                if (!(u < -e || u > 1.0 + e)) {
+                    const V3 q = cross(s, mk(p[3], p[4], p[5]));
+                    const double v = f * dot(d, q);
+                    if (!(v < -e || u + v > 1.0 + e)) {
+                        const double t = f * dot(mk(p[6], p[7], p[8]), q);
+                        // equal distances: the face latest in leaf order wins, as in mesh_collide_packet
+                        if (!(t < tmin || t > bh.t) && !(bh.hit && t == bh.t && face < bh.prim)) {
+                            bh.hit = true;
+                            bh.tmax32 = up32(t - T);
+                            bh.prim = face;
+                            bh.t = t; bh.u = u; bh.v = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// TextureImage.At (texture_image.go:87-188) with the image's description in scalars and the four texels of a bilinear
+// sample fetched together: image_at (dev_shade.h) for the kernel whose every hit samples the same image.
+RT_DEV V3 image_at_uniform(const uint8_t* px, int w, int h, int format, int interp, int wrap, double u, double v) {
+    if (wrap == RT_WRAP_CLAMP) {
+        u = go_min(go_max(u, 0.0), 1.0);
+        v = go_min(go_max(v, 0.0), 1.0);
+    } else {
+        u = u - floor(u);
+        v = v - floor(v);
+    }
+    v = 1.0 - v;
+    const double x = u * (double)(w - 1);
+    const double y = v * (double)(h - 1);
+    uint32_t c[3];
+    if (interp == RT_INTERP_BILINEAR) {
+        const int x0 = (int)floor(x), y0 = (int)floor(y);
+        const double fx = x - (double)x0, fy = y - (double)y0;
+        const int xa = clampi(x0, 0, w - 1), xb = clampi(x0 + 1, 0, w - 1), ya = clampi(y0, 0, h - 1), yb = clampi(y0 + 1, 0, h - 1);
+        uint32_t t[4][3];
+        if (format == RT_IMG_RGBA16) {
+            const uint2* q = reinterpret_cast<const uint2*>(px);
+            const uint2 a = q[(size_t)ya * w + xa], b = q[(size_t)ya * w + xb], cc = q[(size_t)yb * w + xa], dd = q[(size_t)yb * w + xb];
+            const uint2 all[4] = {a, b, cc, dd};
+#pragma unroll
+            for (int k = 0; k < 4; k++) { t[k][0] = all[k].x & 0xffffu; t[k][1] = all[k].x >> 16; t[k][2] = all[k].y & 0xffffu; }
+        } else {  // color.NRGBA.RGBA(): v = v * 0x101 * a / 0xff
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(px);
+            const uint32_t all[4] = {q[(size_t)ya * w + xa], q[(size_t)ya * w + xb], q[(size_t)yb * w + xa], q[(size_t)yb * w + xb]};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t a = all[k] >> 24;
+                uint32_t r = all[k] & 0xffu, g = (all[k] >> 8) & 0xffu, b = (all[k] >> 16) & 0xffu;
+                r |= r << 8; g |= g << 8; b |= b << 8;
+                if (a != 0xff) {  // opaque texels (nearly all of them) keep v * 0x101
+                    r *= a; r /= 0xff;
+                    g *= a; g /= 0xff;
+                    b *= a; b /= 0xff;
+                }
+                t[k][0] = r; t[k][1] = g; t[k][2] = b;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double c0 = (double)t[0][k] * (1 - fx) + (double)t[1][k] * fx;
+            const double c1 = (double)t[2][k] * (1 - fx) + (double)t[3][k] * fx;
+            c[k] = (uint32_t)(uint16_t)(c0 * (1 - fy) + c1 * fy);  // uint16(r) of color.NRGBA64
+        }
+    } else {
+        DImage im;
+        im.px = px; im.w = w; im.h = h; im.format = format; im.pad = 0;
+        texel16(im, (int)round(x), (int)round(y), c);  // math.Round: half away from zero
+    }
+    const double r65535 = 1.0 / 65535.0;  // c / 65535.0 (texture_image.go:183-187), see div_by: exact for every 16-bit c
+    return mk(div_by((double)c[0], 65535.0, r65535), div_by((double)c[1], 65535.0, r65535), div_by((double)c[2], 65535.0, r65535));
+}
+
+// Two float64 in [0, 1) from the four words of a Philox block, as Rng::float64 makes them: (bits >> 11) * 2^-53 of the
+// low and the high 64 bits.  hi * 2^-32 and (lo >> 11) * 2^-53 have no bit in common, so their sum is exact.
+RT_DEV double draw53(uint32_t lo, uint32_t hi) { return __builtin_fma((double)hi, 0x1.0p-32, (double)(lo >> 11) * 0x1.0p-53); }
+
+}  // namespace rt

@@ -79,6 +79,12 @@ struct Replica {
     double* staging = nullptr;     // pinned host memory: the way to the inbox when the two devices have no direct path
     size_t staging_doubles = 0;
     hipEvent_t done = nullptr;     // recorded on `stream` when this replica's share of a frame is finished
+    // Pixel-beam tables (scenes the beam kernel can render: allocated with the scene, filled by k_beam_prepare whenever a
+    // frame's camera direction differs from beam_dir)
+    BeamTables beam{};
+    int64_t beam_faces = 0;
+    double beam_dir[3] = {0, 0, 0};
+    bool beam_dir_valid = false;
 };
 
 }  // namespace rt

@@ -19,6 +19,7 @@
 
 #include "dev_bvh.h"
 #include "dev_shade.h"
+#include "dev_beam.h"
 
 namespace rt {
 
@@ -852,6 +853,9 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                 }
                 bool walking = beam_long;  // wave-uniform
                 if (walking && p == pb) beam_setup(cam, pass.dx, pass.dy, m, lx, y, px_state);  // this round's walk starts over
+#ifdef RT_VISIT_STATS
+                const long long faces_t0 = clock64();
+#endif
                 do {
                     int n = beam_first;
                     if (walking) {
@@ -873,6 +877,9 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                         walking = __builtin_amdgcn_readfirstlane(px_state[12]) != kFastEmpty;
                     }
                 } while (walking);
+#ifdef RT_VISIT_STATS
+                RT_STAT(12, clock64() - faces_t0);
+#endif
                 if (sound) {
                     if (bh.hit) {
                         h.c.t = bh.t; h.c.u = bh.u; h.c.v = bh.v;
@@ -985,6 +992,297 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         sub = __shfl(sub, 0, 64);
         primary_item<MODE, MESH_ONLY, SHADE, BEAM, NO_MESH>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
                                              reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left, n_culled, rot, vc);
+        if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
+    }
+    if (p == 0) {  // the tallies are per wave already
+        Counters::Tally& t = counters->tally[blockIdx.x & (kTallyStripes - 1)];
+        if (n_total) atomicAdd(&t.total, (unsigned long long)n_total);
+        if (n_left) atomicAdd(&t.left, (unsigned long long)n_left);
+        if (n_culled) atomicAdd(&t.culled, (unsigned long long)n_culled);
+    }
+    report_overflow(counters, vc);
+}
+
+// ---- pixel beams: the primary kernel of orthographic frames of one emitting mesh ------------------------------------
+//
+// renderPixel (render.go:186-217) + tracePath (render.go:142-183) for a scene of one untransformed mesh whose material
+// only emits, under an orthographic camera, 64 lanes on the samples of one pixel: the tree is walked once per pixel for
+// the bundle of its rays ("pixel beams", dev_bvh.h), the rounds test the listed faces only, against tables prepared
+// for the camera's direction (dev_beam.h).  The persistent single-wave workgroups and their per-XCD queues are
+// k_primary's.
+#ifndef RT_BEAM_WAVES
+#define RT_BEAM_WAVES 4
+#endif
+
+// The tables of dev_beam.h for direction (dx, dy, dz): one thread per face, leaf order.
+__global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, double dy, double dz, BeamFace32* __restrict__ f32,
+                                                         BeamFace64* __restrict__ f64, double* __restrict__ uv) {
+    const DMesh& m = sc.meshes[sc.nodes[0].index];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m.n_faces) return;
+    const double* pos = sc.prim_pos + (m.prim_off + i) * 9;
+    const V3 p0 = ld3(pos), p1 = ld3(pos + 3), p2 = ld3(pos + 6), d = mk(dx, dy, dz);
+    // shape_mesh.go:99-110, as mt_core computes it for every ray
+    const V3 edge1 = p1 - p0;
+    const V3 edge2 = p2 - p0;
+    const V3 h = cross(d, edge2);
+    const double a = dot(edge1, h);
+    const bool never = a > -1e-8 && a < 1e-8;
+    const double f = 1 / a;
+    BeamFace64 o;
+    st3(o.p0, p0); st3(o.e1, edge1); st3(o.e2, edge2); st3(o.h, h);
+    o.f = never ? __longlong_as_double(0x7ff8000000000000ll) : f;
+    o.pad = 0;
+    f64[i] = o;
+    const Tri32 t = sc.prim_tri32[m.prim_off + i];
+    BeamFace32 q;
+    {
+#pragma clang fp contract(fast)
+        const float fx = (float)dx, fy = (float)dy, fz = (float)dz;
+        const float hx = fy * t.e2[2] - fz * t.e2[1], hy = fz * t.e2[0] - fx * t.e2[2], hz = fx * t.e2[1] - fy * t.e2[0];
+        const float gx = t.e1[1] * fz - t.e1[2] * fy, gy = t.e1[2] * fx - t.e1[0] * fz, gz = t.e1[0] * fy - t.e1[1] * fx;  // e1 x d
+        const float a32 = t.e1[0] * hx + t.e1[1] * hy + t.e1[2] * hz;
+        const float err_d = kErr * sqrtf(fx * fx + fy * fy + fz * fz), err_r = err_d * m.radius;
+        const float eu = err_r * t.len2, ev = err_r * t.len1, ea = err_d * t.len1 * t.len2;
+        const float aa = fabsf(a32), sg = a32 < 0 ? -1.0f : 1.0f;
+        const float inf = __builtin_inff();
+        q.p0[0] = t.p0[0]; q.p0[1] = t.p0[1]; q.p0[2] = t.p0[2];
+        q.h[0] = sg * hx; q.h[1] = sg * hy; q.h[2] = sg * hz;
+        q.g[0] = sg * gx; q.g[1] = sg * gy; q.g[2] = sg * gz;
+        if (never) {  // rejected before any ray is looked at
+            q.h[0] = q.h[1] = q.h[2] = q.g[0] = q.g[1] = q.g[2] = 0.0f;
+            q.neg_eu = inf; q.neg_ev = inf; q.lim = -inf;
+        } else if (!(aa > ea)) {  // sign of a uncertain in float32 (grazing): float64 decides
+            q.neg_eu = -inf; q.neg_ev = -inf; q.lim = inf;
+        } else {
+            q.neg_eu = -eu; q.neg_ev = -ev; q.lim = aa + eu + ev + ea;
+        }
+    }
+    f32[i] = q;
+    const double* src = sc.face_uv + (m.face_off + sc.prim_face[m.prim_off + i]) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) uv[i * 6 + k] = src[k];
+}
+
+// One work item: pass.block_px (at most kBeamPixels) consecutive pixels of tile v, all samples of the pass.  Dynamic LDS:
+// the walking lanes' stacks (lane j: 2 * cap dwords at j * 2 * cap), then at pass.beam_offset the lists (kBeamPixels x
+// kBeamCands triples), the walks' states and 16 dwords for beam_cull_item32.
+template <bool IMG>
+RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const BeamTables& bt, double* __restrict__ film, long long v,
+                      uint32_t sub, int p, int cap, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, VisitCounts& vc) {
+    const int rounds = (pass.sample_count + 63) >> 6;
+    const int64_t tile = pass.tile_begin + v;
+    const int64_t group = tile >> 6;
+    const int w = (int)(tile & 63);
+    const int tile_x = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8;
+    const int tile_y = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8;
+    const double inv_dx = 1.0 / (double)pass.dx, inv_dy = 1.0 / (double)pass.dy;  // for div_by: the divisions of render.go:202-210
+    int32_t* const beam_cand = dyn_lds + pass.beam_offset;
+    int32_t* const beam_state = beam_cand + kBeamPixels * kBeamCands * 3;
+    const DMesh& m = sc.meshes[sc.nodes[0].index];
+    const FastNode* const tree = sc.fast_nodes + m.beam_off;
+    // lane j walks the bundle of pixel j of the item: the first instalment of its list, and whether there is more
+    if (p < pass.block_px) {
+        int32_t* const st = beam_state + p * kBeamStateDwords;
+        const int pix = (int)sub * pass.block_px + p;
+        const int lx = tile_x + (pix & 7), ly = tile_y + (pix >> 3);
+        const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);
+        int32_t found = 0;
+        if (lx < pass.dx && ly < pass.local_rows && row < pass.dy) {
+#ifdef RT_VISIT_STATS
+            uint32_t steps = 0;
+            if (beam_setup(cam, pass.dx, pass.dy, m, lx, pass.dy - 1 - row, st)) {
+                found = beam_fill(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow, steps);
+#else
+            if (beam_setup(cam, pass.dx, pass.dy, m, lx, pass.dy - 1 - row, st)) {
+                found = beam_fill(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow);
+#endif
+                if (st[12] != kFastEmpty) found |= 0x100;  // the list goes on: this pixel's rounds walk it in instalments
+            }
+        }
+        st[15] = found;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    beam_cull_item32(bt.f32, beam_state, beam_cand, beam_state + kBeamPixels * kBeamStateDwords, pass.block_px, p);
+    if (p < pass.block_px) {
+        const int32_t found = beam_state[p * kBeamStateDwords + 15];
+        if (!(found & 0x100)) beam_suffix_min(beam_cand + p * kBeamCands * 3, found & 0xff);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // what every hit of the item samples (wave-uniform: scalar loads)
+    const rt_material& mat = sc.materials[sc.nodes[0].material];
+    const uint8_t* img_px = nullptr;
+    int img_w = 0, img_h = 0, img_format = 0, img_interp = 0, img_wrap = 0;
+    if (IMG) {
+        const rt_texture& tx = sc.textures[mat.texture];
+        const DImage& im = sc.images[tx.image];
+        img_px = im.px; img_w = im.w; img_h = im.h; img_format = im.format;
+        img_interp = tx.interp; img_wrap = tx.wrap;
+    }
+    const V3 d = ld3(cam.dir);  // every ray of an orthographic camera has the camera's direction (camera_orthographic.go:44)
+    const bool d_sound = !bad3(d);
+    for (int pb = 0; pb < pass.block_px; pb++) {
+        // all 64 lanes are on this pixel: everything about it is wave-uniform
+        const int pix = (int)sub * pass.block_px + pb;
+        const int lx = tile_x + (pix & 7);
+        const int ly = tile_y + (pix >> 3);
+        const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
+        if (!(lx < pass.dx && ly < pass.local_rows && row < pass.dy)) continue;          // outside the frame
+        const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
+        const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
+        int32_t* const px_state = beam_state + pb * kBeamStateDwords;
+        int32_t* const px_cand = beam_cand + pb * kBeamCands * 3;
+        const int32_t found = __builtin_amdgcn_readfirstlane(px_state[15]);
+        const int beam_first = found & 0xff;
+        const bool beam_long = (found & 0x100) != 0;
+        const double beam_T = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[11]) << 32) |
+                                                               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[10])));
+        if (pass.cull_pixels && found == 0) {  // nothing listed: no ray through this pixel can hit, whatever its jitter
+            n_total += (uint32_t)pass.sample_count;
+            n_left += (uint32_t)pass.sample_count;
+            n_culled += (uint32_t)pass.sample_count;
+            continue;
+        }
+        // origin of the bundle's float32 frame: a ray's origin in it is o + (d T - centre)
+        const V3 shift = d * beam_T - ld3(m.center);
+        const double xd = (double)lx, yd = (double)y;
+        const uint32_t ctr0 = (uint32_t)(y * pass.dx + lx);
+        V3 acc = mk(0, 0, 0);
+        for (int round = 0; round < rounds; round++) {
+            const int k = (round << 6) + p;
+            const bool traced = k < pass.sample_count;
+            const int left_here = pass.sample_count - (round << 6);
+            n_total += (uint32_t)(left_here < 64 ? left_here : 64);
+            // the two jitter draws: draws 0 and 1 of the stream (pixel, sample, path 1), one Philox block.  The key schedule is
+            // rebuilt from the seed in every round (scalar additions): kept across the rounds it would occupy twenty scalar
+            // registers that the list walk needs.
+            uint32_t k0 = pass.seed_lo, k1 = pass.seed_hi;
+            asm volatile("" : "+s"(k0), "+s"(k1));
+            uint32_t blk[4] = {ctr0, (uint32_t)(pass.sample_begin + k), 1u, 0u};
+            philox4x32_10(blk, k0, k1);
+            const double fs = div_by(xd + draw53(blk[0], blk[1]), (double)pass.dx, inv_dx);  // render.go:202-210
+            const double ft = div_by(yd + draw53(blk[2], blk[3]), (double)pass.dy, inv_dy);
+            // camera_orthographic.go:24-46
+            const V3 o = (ld3(cam.from) + ld3(cam.u) * (cam.fov_w * (fs - 0.5))) + ld3(cam.v) * (cam.fov_h * (ft - 0.5));
+            bool sound = traced && d_sound;
+            if (!bt.safe_camera) sound = sound && !bad3(o);  // render.go:147-150
+            BeamHit bh{false, __builtin_inff(), 0, kMaxFloat, 0, 0};
+            const float fx = (float)(o.x + shift.x), fy = (float)(o.y + shift.y), fz = (float)(o.z + shift.z);
+            bool walking = beam_long;  // wave-uniform
+            if (walking && p == pb) beam_setup(cam, pass.dx, pass.dy, m, lx, y, px_state);  // this round's walk starts over
+#ifdef RT_VISIT_STATS
+            const long long faces_t0 = clock64();
+#endif
+            do {
+                int n = beam_first;
+                if (walking) {
+#ifdef RT_VISIT_STATS
+                    uint32_t again = 0;
+                    if (p == pb) px_state[15] = beam_fill(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, vc.overflow, again);
+#else
+                    if (p == pb) px_state[15] = beam_fill(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, vc.overflow);
+#endif
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    n = __builtin_amdgcn_readfirstlane(px_state[15]);
+                }
+                if (n > 0) beam_test_prepared(bt, o, d, fx, fy, fz, beam_T, px_cand, n, !beam_long, kEps, sound, bh);
+                if (walking) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    walking = __builtin_amdgcn_readfirstlane(px_state[12]) != kFastEmpty;
+                }
+            } while (walking);
+#ifdef RT_VISIT_STATS
+            RT_STAT(12, clock64() - faces_t0);
+            RT_STAT(10, 1);
+#endif
+            n_left += (uint32_t)__popcll(__ballot(sound && !bh.hit));  // render.go:170-173
+            if (sound && bh.hit) {
+                if (IMG) {  // Face.Collide's texture coordinates (shape_mesh.go:131-140), Emitter.Resolve (material_emitter.go:22-25) with radiance (1, 1, 1)
+                    const double* uv6 = bt.uv + (size_t)bh.prim * 6;
+                    const double wgt = 1 - bh.u - bh.v;
+                    const double cu = (uv6[0] * wgt + uv6[2] * bh.u) + uv6[4] * bh.v;
+                    const double cv = (uv6[1] * wgt + uv6[3] * bh.u) + uv6[5] * bh.v;
+                    const V3 em = image_at_uniform(img_px, img_w, img_h, img_format, img_interp, img_wrap, cu, cv);
+                    acc.x += em.x; acc.y += em.y; acc.z += em.z;
+                } else {  // any other emitting material, through the code every other kernel runs
+                    SceneHit h;
+                    h.c.t = bh.t; h.c.u = bh.u; h.c.v = bh.v;
+                    h.node = 0;
+                    h.leaf = bh.prim;
+                    h.rec_leaf = bh.prim;
+                    h.prim = sc.prim_face[m.prim_off + bh.prim];
+                    V3 em;
+                    const Ray r{o, d};
+                    if (after_closest(sc, r, mk(1, 1, 1), true, h, em) == 1) { acc.x += em.x; acc.y += em.y; acc.z += em.z; }
+                }
+            }
+        }
+        // sum over the 64 lanes of the pixel, in the order k_primary adds them
+        for (int off = 32; off > 0; off >>= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64);
+        }
+        if (p == 0) {  // the only writer of this pixel during the launch
+            double* f = film + (size_t)pixel * 3;
+            if (acc.x != 0) f[0] += acc.x;
+            if (acc.y != 0) f[1] += acc.y;
+            if (acc.z != 0) f[2] += acc.z;
+        }
+    }
+}
+
+template <bool IMG>
+__global__ void __launch_bounds__(kTraceBlock, RT_BEAM_WAVES) k_beam(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, Counters* __restrict__ counters,
+                                                                     BeamTables bt, double* __restrict__ film) {
+    const DCamera& cam = *camp;
+    const int p = (int)threadIdx.x;
+    const int64_t n_tiles = pass.n_pixels >> 6;
+    const uint32_t n_sub = 64u / (uint32_t)pass.block_px;  // items per tile
+    const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
+    uint32_t n_total = 0, n_left = 0, n_culled = 0;
+    VisitCounts vc{0, 0};
+    // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
+    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
+        const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
+        const uint32_t idx = item / n_sub;
+        long long cand = -1;
+        if (pass.order) {
+            if (idx < pass.queue_len[owner]) cand = pass.order[pass.queue_off[owner] + idx];
+        } else {
+            cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
+        }
+        tile_out = (cand >= 0 && cand < n_tiles) ? cand : -1;
+        sub_out = item - idx * n_sub;
+    };
+    // the item after the current one is drawn while the current one is traced (the atomic's round trip is off the critical path)
+    long long ahead_v = -1;
+    uint32_t ahead_sub = 0;
+    if (p == 0) draw(xcd, ahead_v, ahead_sub);
+    for (;;) {
+        long long v = -1;
+        uint32_t sub = 0;
+        if (p == 0) {
+            if (ahead_v >= 0) {
+                v = ahead_v;
+                sub = ahead_sub;
+                draw(xcd, ahead_v, ahead_sub);
+            } else {  // own queue exhausted (cursors only grow): take from the other XCDs' queues
+                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub);
+            }
+        }
+        // lane 0's values, as scalars: everything derived from them (the item's pixels) stays in scalar registers
+        const int v_lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll)), v_hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+        v = (long long)(((unsigned long long)(uint32_t)v_hi << 32) | (uint32_t)v_lo);
+        if (v < 0) break;
+        sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
+        const long long t_start = pass.cost ? clock64() : 0;
+        beam_item<IMG>(sc, cam, pass, bt, film, v, sub, p, sc.stack_pairs, n_total, n_left, n_culled, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
     if (p == 0) {  // the tallies are per wave already
@@ -1689,6 +1987,42 @@ static unsigned persistent_grid(K kernel, size_t lds, int block = kTraceBlock) {
 }
 
 int beam_pixels_max() { return kBeamPixels; }
+
+void launch_beam_prepare(const DScene& sc, int64_t n_faces, const double dir[3], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s) {
+    if (n_faces <= 0) return;
+    hipLaunchKernelGGL(k_beam_prepare, dim3(blocks_for((size_t)n_faces)), dim3(kBlock), 0, s, sc, dir[0], dir[1], dir[2], f32, f64, uv);
+}
+
+size_t beam_table_bytes(int64_t n_faces, size_t* off_f64, size_t* off_uv) {
+    const size_t n = (size_t)n_faces, a = (n * sizeof(BeamFace32) + 255) & ~(size_t)255, b = (n * sizeof(BeamFace64) + 255) & ~(size_t)255;
+    if (off_f64) *off_f64 = a;
+    if (off_uv) *off_uv = a + b;
+    return a + b + n * 6 * sizeof(double);
+}
+
+// The pixel-beam launch: when the pass allows it (64 lanes per pixel, items of at most kBeamPixels pixels).  False: the caller
+// launches k_primary instead.
+bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Counters* counters, const BeamTables& bt, double* film, hipStream_t s) {
+    if (pass.n_pixels <= 0) return true;
+    if (pass.log2_s != 6 || pass.block_px > kBeamPixels || pass.spp <= 1) return false;
+    // the stacks of the kBeamPixels walking lanes, a (reference, distance) pair per level each; behind them the lists, the
+    // walks' states and beam_cull_item32's prefix sums
+    size_t lds = (size_t)kBeamPixels * 2 * sc.stack_pairs * sizeof(int32_t);
+    lds = (lds + 7) & ~(size_t)7;
+    PassDesc pd = pass;
+    pd.acc_offset = 0;
+    pd.beam_offset = (int32_t)(lds / sizeof(int32_t));
+    lds += ((size_t)kBeamPixels * (kBeamCands * 3 + kBeamStateDwords) + 16) * sizeof(int32_t);
+    const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
+    auto go = [&](auto kernel) {
+        const unsigned resident = persistent_grid(kernel, lds);
+        const unsigned waves = std::min(resident, (tiles + 7u) & ~7u);
+        hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), lds, s, sc, cam, pd, counters, bt, film);
+    };
+    if (bt.image) go(k_beam<true>);
+    else go(k_beam<false>);
+    return true;
+}
 
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
                     double* film, hipStream_t s, bool beam) {

@@ -606,6 +606,24 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
     // Pixel beams (one tree walk per pixel instead of one per 64 samples, see dev_bvh.h): parallel rays through one mesh.
     const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC && !getenv("RT_NO_BEAM");
+    const bool beam_tables = beam && rep.beam_faces > 0 && !getenv("RT_OLD_BEAM");
+    if (beam_tables) {
+        // the tables belong to a direction: every ray of the frame has the camera's (camera_orthographic.go:44)
+        if (!rep.beam_dir_valid || std::memcmp(rep.beam_dir, cam.dir, sizeof(rep.beam_dir)) != 0) {
+            launch_beam_prepare(rep.dev, rep.beam_faces, cam.dir, const_cast<BeamFace32*>(rep.beam.f32), const_cast<BeamFace64*>(rep.beam.f64),
+                                const_cast<double*>(rep.beam.uv), stream);
+            HIP_TRY(hipGetLastError());
+            std::memcpy(rep.beam_dir, cam.dir, sizeof(rep.beam_dir));
+            rep.beam_dir_valid = true;
+        }
+        // Origins are from + u a + v b with |a| <= |FOVWidth| / 2, |b| <= |FOVHeight| / 2: finite constants far from the
+        // float64 range cannot produce a NaN or an infinity, so the guard of render.go:147-150 never fires and is left out
+        bool safe = true;
+        for (int k = 0; k < 3; k++)
+            for (double c : {cam.from[k], cam.u[k], cam.v[k], cam.dir[k]}) safe = safe && std::isfinite(c) && std::fabs(c) < 1e150;
+        safe = safe && std::isfinite(cam.fov_w) && std::isfinite(cam.fov_h) && std::fabs(cam.fov_w) < 1e150 && std::fabs(cam.fov_h) < 1e150;
+        rep.beam.safe_camera = safe ? 1 : 0;
+    }
     const bool item_rays_fixed = getenv("RT_ITEM_RAYS") != nullptr;
     if (const char* e = getenv("RT_ITEM_RAYS")) item_rays = std::max(1, atoi(e));
     for (int s0 = s_first; s0 < s_end;) {
@@ -680,7 +698,8 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 HIP_TRY(events.next(&ev));
                 HIP_TRY(hipEventRecord(ev->a, stream));
             }
-            launch_primary(rep.dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream, beam);
+            if (!(beam_tables && launch_beam(rep.dev, w.d_camera, pass, q.counters, rep.beam, film, stream)))
+                launch_primary(rep.dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream, beam);
             if (pass.order) culled_rays += w.culled_pixels * (uint64_t)s_count;  // tiles the schedule leaves out: nothing to trace
             if (timed) HIP_TRY(hipEventRecord(ev->b, stream));
             HIP_TRY(hipGetLastError());

@@ -640,6 +640,18 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             dev.pair_radius = pair_radius;
         }
         HIP_TRY(rep->mem.upload(walk_nodes, &dev.walk_nodes));
+        if (beam_scene) {  // the pixel-beam kernel's per-direction tables: filled when a frame's camera is known
+            size_t off_f64 = 0, off_uv = 0;
+            const int64_t n = (int64_t)d->meshes[0].n_faces;
+            uint8_t* base = nullptr;
+            HIP_TRY(rep->mem.alloc(beam_table_bytes(n, &off_f64, &off_uv), &base));
+            rep->beam.f32 = reinterpret_cast<const BeamFace32*>(base);
+            rep->beam.f64 = reinterpret_cast<const BeamFace64*>(base + off_f64);
+            rep->beam.uv = reinterpret_cast<const double*>(base + off_uv);
+            rep->beam.image = d->materials[nodes[0].material].kind == RT_MAT_EMITTER &&
+                              d->textures[d->materials[nodes[0].material].texture].kind == RT_TEX_IMAGE;
+            rep->beam_faces = n;
+        }
         HIP_TRY(hipEventCreateWithFlags(&rep->done, hipEventDisableTiming));
         if (r > 0) HIP_TRY(hipStreamCreateWithFlags(&rep->stream, hipStreamNonBlocking));
         sc->replicas.push_back(std::move(rep));

@@ -128,6 +128,38 @@ struct DScene {
     int32_t sort_kinds;  // 1: the nodes' materials run more than one kind of Resolve code: hits are taken in the order of their materials (k_shade)
 };
 
+// ---- tables of the pixel-beam kernel (dev_beam.h): per face of the mesh and per camera direction ----
+
+// float32 pre-test of one face for one direction, mesh-centred frame.  h and g carry the sign of a, so that "inside" always
+// means us >= neg_eu, vs >= neg_ev, us + vs <= lim.  A face whose float64 test can never pass (|a| < 1e-8) has
+// neg_eu = +inf (always rejected); one whose sign of a float32 cannot decide has neg_eu = neg_ev = -inf, lim = +inf
+// (never rejected: float64 decides).
+struct BeamFace32 {
+    float p0[3];
+    float h[3];  // sign(a) d x e2
+    float g[3];  // sign(a) e1 x d
+    float neg_eu, neg_ev, lim;
+};
+static_assert(sizeof(BeamFace32) == 48, "three 16-byte scalar loads");
+
+// The ray-independent half of Face.Collide for one direction.  f is NaN for a face the reference rejects whatever the ray.
+struct BeamFace64 {
+    double p0[3], e1[3], e2[3], h[3];
+    double f;
+    double pad;
+};
+static_assert(sizeof(BeamFace64) == 112, "seven 16-byte scalar loads");
+
+// What the beam kernel reads besides the scene: the tables above and the faces' texture coordinates (6 per face), all in
+// the leaf order of the mesh's trees.
+struct BeamTables {
+    const BeamFace32* f32;
+    const BeamFace64* f64;
+    const double* uv;
+    int32_t safe_camera;  // 1: every origin the camera can produce is finite (the host has looked at its constants): the NaN / Inf guard of render.go:147-150 cannot fire
+    int32_t image;        // 1: the material is an Emitter whose texture is a TextureImage (the kernel samples it in line)
+};
+
 struct DCamera {
     int32_t kind, pad;
     double from[3];
