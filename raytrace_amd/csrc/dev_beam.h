@@ -48,9 +48,22 @@ RT_DEV bool face32_rejects_bundle(const BeamFace32& t, float ox, float oy, float
     return us + dU < t.neg_eu || vs + dV < t.neg_ev || (us - dU) + (vs - dV) > t.lim;
 }
 
+// What a pixel's rounds test, when it is short enough: the faces that survive beam_cull_item32, in list order, each with its
+// prepared float32 form in LDS -- kBeamFaceDwords dwords: BeamFace32 (12), the entry distance of its leaf (suffix minimum), its
+// position in leaf order.  A round then reads no memory until a face passes the pre-test.  A pixel with more survivors
+// keeps walking its leaf list (beam_test_prepared).
+#ifndef RT_BEAM_FACES
+#define RT_BEAM_FACES 12
+#endif
+constexpr int kBeamFacesMax = RT_BEAM_FACES;
+constexpr int kBeamFaceDwords = 16;
+constexpr int kBeamCullDwords = 32;  // beam_cull_item32's own LDS: prefix sums of the list lengths (9), survivors per pixel (8)
+
 // beam_cull_item (dev_bvh.h) on the prepared faces: kBeamLeafFaces lanes per listed leaf, one per face, each testing its
-// face against the bundle of the leaf's pixel; the survivors become the leaf's mask.  Must be entered by all 64 lanes.
-RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32_t* beam_cand, int32_t* prefix, int n_px, int lane) {
+// face against the bundle of the leaf's pixel; the survivors become the leaf's mask and are appended, in list order, to the
+// pixel's compact array (entry 12 holds the position of the face's leaf in the list until beam_patch_distances has run).
+// beam_state[j * kBeamStateDwords + 25] receives the number of survivors of pixel j.  Must be entered by all 64 lanes.
+RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32_t* beam_cand, int32_t* prefix, int32_t* compact, int n_px, int lane) {
     int len = 0;
     if (lane < n_px) {
         const int32_t v = beam_state[lane * kBeamStateDwords + 15];
@@ -62,7 +75,11 @@ RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32
         const int o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
-    if (lane < kBeamPixels) prefix[lane + 1] = incl;
+    int32_t* const count = prefix + 9;
+    if (lane < kBeamPixels) {
+        prefix[lane + 1] = incl;
+        count[lane] = 0;
+    }
     if (lane == 0) prefix[0] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -71,24 +88,121 @@ RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32
         const int s = base + lane / kBeamLeafFaces, q = lane & (kBeamLeafFaces - 1);
         bool keep = false;
         int32_t* entry = beam_cand;
+        int j = 0, at = 0;
+        int32_t face = 0;
+        BeamFace32 t{};
         if (s < total) {
-            int j = 0;
 #pragma unroll
             for (int k = 1; k < kBeamPixels; k++)
                 if (s >= prefix[k]) j = k;
-            entry = beam_cand + (j * kBeamCands + (s - prefix[j])) * 3;
+            at = s - prefix[j];
+            entry = beam_cand + (j * kBeamCands + at) * 3;
             const uint32_t code = (uint32_t)~entry[0];
             if (q <= (int)(code & (uint32_t)(kBeamLeafFaces - 1))) {
                 const int32_t* st = beam_state + j * kBeamStateDwords;
-                keep = !face32_rejects_bundle(faces[(int32_t)(code >> RT_BEAM_LEAF_BITS) + q], __int_as_float(st[16]), __int_as_float(st[17]),
-                                              __int_as_float(st[18]), __int_as_float(st[19]), __int_as_float(st[20]), __int_as_float(st[21]));
+                face = (int32_t)(code >> RT_BEAM_LEAF_BITS) + q;
+                t = faces[face];
+                keep = !face32_rejects_bundle(t, __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]), __int_as_float(st[19]),
+                                              __int_as_float(st[20]), __int_as_float(st[21]));
             }
         }
         const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
         if (s < total && q == 0) entry[2] = (int32_t)((kept >> (lane & (64 - kBeamLeafFaces))) & (unsigned long long)kBeamLeafMask);
+        if (keep) {  // survivors of one pixel sit in consecutive lanes: the slot is the pixel's count so far + the survivors below this lane
+            const int first = prefix[j] - base;
+            const int lo_lane = first > 0 ? first * kBeamLeafFaces : 0;
+            const unsigned long long mine = kept & ((1ull << lane) - 1ull) & ~((1ull << lo_lane) - 1ull);
+            const int slot = count[j] + (int)__popcll(mine);
+            if (slot < kBeamFacesMax) {
+                int32_t* e = compact + (j * kBeamFacesMax + slot) * kBeamFaceDwords;
+                e[0] = __float_as_int(t.p0[0]); e[1] = __float_as_int(t.p0[1]); e[2] = __float_as_int(t.p0[2]);
+                e[3] = __float_as_int(t.h[0]); e[4] = __float_as_int(t.h[1]); e[5] = __float_as_int(t.h[2]);
+                e[6] = __float_as_int(t.g[0]); e[7] = __float_as_int(t.g[1]); e[8] = __float_as_int(t.g[2]);
+                e[9] = __float_as_int(t.neg_eu); e[10] = __float_as_int(t.neg_ev); e[11] = __float_as_int(t.lim);
+                e[12] = at;
+                e[13] = face;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_px) {  // this iteration's survivors of pixel `lane`
+            int lo = (prefix[lane] - base) * kBeamLeafFaces, hi = (prefix[lane + 1] - base) * kBeamLeafFaces;
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > 64 ? 64 : hi;
+            if (lo < hi) {
+                const unsigned long long upto = hi >= 64 ? ~0ull : (1ull << hi) - 1ull;
+                count[lane] += (int)__popcll(kept & upto & ~((1ull << lo) - 1ull));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < n_px) beam_state[lane * kBeamStateDwords + 25] = count[lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// After beam_suffix_min: every compact entry takes the entry distance its leaf now carries (a suffix minimum, so the
+// distances of a pixel's entries never decrease and a round can stop at the first one beyond its hit).
+RT_DEV void beam_patch_distances(const int32_t* beam_state, const int32_t* beam_cand, int32_t* compact, int n_px, int lane) {
+    for (int k = lane; k < n_px * kBeamFacesMax; k += 64) {
+        const int j = k / kBeamFacesMax, i = k - j * kBeamFacesMax;
+        if (i < beam_state[j * kBeamStateDwords + 25]) {
+            int32_t* e = compact + k * kBeamFaceDwords;
+            e[12] = beam_cand[(j * kBeamCands + e[12]) * 3 + 1];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// One prepared face (float64) against this lane's ray: shape_mesh.go:110-124 with edge1, edge2, h, f as prepared; keeps the
+// closest hit in bh.  Entered by all lanes of the wave; `maybe` = this lane's ray passed the pre-test.
+RT_DEV void beam_face64(const BeamTables& bt, int32_t face, V3 o, V3 d, double T, double tmin, bool maybe, BeamHit& bh) {
+    const RT_CONST_AS double* p = (const RT_CONST_AS double*)(bt.f64 + face);
+    const double f = p[12];
+    // a face the reference rejects whatever the ray (shape_mesh.go:107-109): f is NaN, all bits of its exponent set
+    if (((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(__double_as_longlong(f) >> 32)) & 0x7ff00000u) == 0x7ff00000u) return;
+    if (maybe) {
+        const double e = 1e-8;
+        const V3 s = o - mk(p[0], p[1], p[2]);
+        const double u = f * dot(s, mk(p[9], p[10], p[11]));
+        if (!(u < -e || u > 1.0 + e)) {
+            const V3 q = cross(s, mk(p[3], p[4], p[5]));
+            const double v = f * dot(d, q);
+            if (!(v < -e || u + v > 1.0 + e)) {
+                const double t = f * dot(mk(p[6], p[7], p[8]), q);
+                // equal distances: the face latest in leaf order wins, as in mesh_collide_packet
+                if (!(t < tmin || t > bh.t) && !(bh.hit && t == bh.t && face < bh.prim)) {
+                    bh.hit = true;
+                    bh.tmax32 = up32(t - T);
+                    bh.prim = face;
+                    bh.t = t; bh.u = u; bh.v = v;
+                }
+            }
+        }
+    }
+}
+
+// The n compact entries of a pixel against this lane's ray.  Must be entered by the lanes of a wave together.
+RT_DEV void beam_test_compact(const BeamTables& bt, V3 o, V3 d, float fx, float fy, float fz, double T, const int32_t* compact, int n, double tmin,
+                              bool sound, BeamHit& bh) {
+    for (int i = 0; i < n; i++) {
+        const int32_t* e = compact + i * kBeamFaceDwords;
+        const float tb = __int_as_float(e[12]);
+        const bool live = sound && tb <= bh.tmax32;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // the distances never decrease: nothing after this entry begins nearer
+        BeamFace32 t;
+        t.p0[0] = __int_as_float(e[0]); t.p0[1] = __int_as_float(e[1]); t.p0[2] = __int_as_float(e[2]);
+        t.h[0] = __int_as_float(e[3]); t.h[1] = __int_as_float(e[4]); t.h[2] = __int_as_float(e[5]);
+        t.g[0] = __int_as_float(e[6]); t.g[1] = __int_as_float(e[7]); t.g[2] = __int_as_float(e[8]);
+        t.neg_eu = __int_as_float(e[9]); t.neg_ev = __int_as_float(e[10]); t.lim = __int_as_float(e[11]);
+        const bool maybe = live && !face32_rejects(t, fx, fy, fz);
+        RT_STAT(3, 1);
+        if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+        RT_STAT(4, 1);
+        beam_face64(bt, __builtin_amdgcn_readfirstlane(e[13]), o, d, T, tmin, maybe, bh);
+    }
 }
 
 // The faces of n listed leaves (those their masks name) against this lane's ray: beam_test (dev_bvh.h) on the prepared
@@ -113,30 +227,7 @@ RT_DEV void beam_test_prepared(const BeamTables& bt, V3 o, V3 d, float fx, float
             RT_STAT(3, 1);
             if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
             RT_STAT(4, 1);
-            const RT_CONST_AS double* p = (const RT_CONST_AS double*)(bt.f64 + face);
-            const double f = p[12];
-            // a face the reference rejects whatever the ray (shape_mesh.go:107-109): f is NaN, all bits of its exponent set
-            if (((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(__double_as_longlong(f) >> 32)) & 0x7ff00000u) == 0x7ff00000u) continue;
-            if (maybe) {
-                // shape_mesh.go:110-124 with edge1, edge2, h, f as prepared; e = 1e-8
-                const double e = 1e-8;
-                const V3 s = o - mk(p[0], p[1], p[2]);
-                const double u = f * dot(s, mk(p[9], p[10], p[11]));
-                if (!(u < -e || u > 1.0 + e)) {
-                    const V3 q = cross(s, mk(p[3], p[4], p[5]));
-                    const double v = f * dot(d, q);
-                    if (!(v < -e || u + v > 1.0 + e)) {
-                        const double t = f * dot(mk(p[6], p[7], p[8]), q);
-                        // equal distances: the face latest in leaf order wins, as in mesh_collide_packet
-                        if (!(t < tmin || t > bh.t) && !(bh.hit && t == bh.t && face < bh.prim)) {
-                            bh.hit = true;
-                            bh.tmax32 = up32(t - T);
-                            bh.prim = face;
-                            bh.t = t; bh.u = u; bh.v = v;
-                        }
-                    }
-                }
-            }
+            beam_face64(bt, face, o, d, T, tmin, maybe, bh);
         }
     }
 }

@@ -873,7 +873,7 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
 // 2^-21 of the mesh radius on top of the boxes' padding.
 
 #ifndef RT_BEAM_PIXELS
-#define RT_BEAM_PIXELS 8
+#define RT_BEAM_PIXELS 4
 #endif
 constexpr int kBeamPixels = RT_BEAM_PIXELS;      // pixels of a work item at most (one lane walks each)
 #ifndef RT_BEAM_CANDS
@@ -939,29 +939,6 @@ RT_DEV bool beam_setup(const DCamera& cam, int32_t dx_img, int32_t dy_img, const
     state[13] = 0;
     state[14] = __float_as_int(t_lo);
     return true;
-}
-
-// tri32_rejects for the whole bundle: true = the float64 test cannot accept this face for ANY ray of the bundle.  With
-// s = o - p0, U = s.(d x e2) and V = s.(e1 x d) are linear in the origin, so over the footprint (|o - centre| <= ext per
-// axis) they stay within dU = sum ext_k |(d x e2)_k| and dV = sum ext_k |(e1 x d)_k| of their values at the centre ray;
-// the face is dropped only when even the most favourable origin violates a bound by more than tri32_rejects' own margins.
-RT_DEV bool beam_rejects_face(const Tri32& t, float ox, float oy, float oz, float ex, float ey, float ez, float dx, float dy, float dz,
-                              float err_r, float err_d) {
-#pragma clang fp contract(fast)
-    const float hx = dy * t.e2[2] - dz * t.e2[1], hy = dz * t.e2[0] - dx * t.e2[2], hz = dx * t.e2[1] - dy * t.e2[0];
-    const float gx = t.e1[1] * dz - t.e1[2] * dy, gy = t.e1[2] * dx - t.e1[0] * dz, gz = t.e1[0] * dy - t.e1[1] * dx;  // e1 x d
-    const float a = t.e1[0] * hx + t.e1[1] * hy + t.e1[2] * hz;
-    const float sx = ox - t.p0[0], sy = oy - t.p0[1], sz = oz - t.p0[2];
-    const float U = sx * hx + sy * hy + sz * hz;
-    const float V = sx * gx + sy * gy + sz * gz;
-    const float slack = 1.0f + 1.0f / 65536.0f;  // the bounds themselves are rounded
-    const float dU = (ex * fabsf(hx) + ey * fabsf(hy) + ez * fabsf(hz)) * slack;
-    const float dV = (ex * fabsf(gx) + ey * fabsf(gy) + ez * fabsf(gz)) * slack;
-    const float eu = err_r * t.len2, ev = err_r * t.len1, ea = err_d * t.len1 * t.len2;
-    const float aa = fabsf(a);
-    if (!(aa > ea)) return false;  // sign of a uncertain: let the samples decide
-    const float us = a < 0 ? -U : U, vs = a < 0 ? -V : V;
-    return us + dU < -eu || vs + dV < -ev || (us - dU) + (vs - dV) > aa + eu + ev + ea;
 }
 
 // One instalment of a pixel's walk: up to kBeamCands leaves, (reference, entry distance, face mask) triples in cand.  The
@@ -1050,53 +1027,6 @@ RT_DEV void beam_suffix_min(int32_t* cand, int n) {
     }
 }
 
-// The whole wave thins the complete lists of an item's pixels out: kBeamLeafFaces lanes per listed leaf, one per face, each
-// testing its face against the bundle of the leaf's pixel (beam_rejects_face); the faces that survive become the
-// leaf's mask.  All the faces of eight leaves are fetched at once, so an item pays a few memory round trips here
-// instead of one per face in every round.  prefix: 9 dwords of LDS.  Must be entered by all 64 lanes.
-RT_DEV void beam_cull_item(const Tri32* tri32, float radius, int32_t* beam_state, int32_t* beam_cand, int32_t* prefix, int n_px, int lane) {
-    int len = 0;
-    if (lane < n_px) {
-        const int32_t v = beam_state[lane * kBeamStateDwords + 15];
-        len = (v & 0x100) ? 0 : (v & 0xff);  // a list that goes on is walked in instalments inside the rounds, unthinned
-    }
-    int incl = len;
-#pragma unroll
-    for (int off = 1; off < kBeamPixels; off <<= 1) {
-        const int o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    if (lane < kBeamPixels) prefix[lane + 1] = incl;
-    if (lane == 0) prefix[0] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int total = __builtin_amdgcn_readfirstlane(prefix[kBeamPixels]);
-    for (int base = 0; base < total; base += 64 / kBeamLeafFaces) {
-        const int s = base + lane / kBeamLeafFaces, q = lane & (kBeamLeafFaces - 1);
-        bool keep = false;
-        int32_t* entry = beam_cand;
-        if (s < total) {
-            int j = 0;
-#pragma unroll
-            for (int k = 1; k < kBeamPixels; k++)
-                if (s >= prefix[k]) j = k;
-            entry = beam_cand + (j * kBeamCands + (s - prefix[j])) * 3;
-            const uint32_t code = (uint32_t)~entry[0];
-            if (q <= (int)(code & (uint32_t)(kBeamLeafFaces - 1))) {
-                const int32_t* st = beam_state + j * kBeamStateDwords;
-                const float dx = __int_as_float(st[22]), dy = __int_as_float(st[23]), dz = __int_as_float(st[24]);
-                const float err_d = kErr * sqrtf(dx * dx + dy * dy + dz * dz);
-                keep = !beam_rejects_face(tri32[(int32_t)(code >> RT_BEAM_LEAF_BITS) + q], __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]),
-                                          __int_as_float(st[19]), __int_as_float(st[20]), __int_as_float(st[21]), dx, dy, dz, err_d * radius, err_d);
-            }
-        }
-        const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
-        if (s < total && q == 0) entry[2] = (int32_t)((kept >> (lane & (64 - kBeamLeafFaces))) & (unsigned long long)kBeamLeafMask);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // A sample's search state over the instalments of its pixel's list.
 struct BeamHit {
     bool hit;
@@ -1105,47 +1035,5 @@ struct BeamHit {
     double t;      // the closest hit so far; before the first one, the search limit
     double u, v;
 };
-
-// The faces of n listed leaves (those their masks name) against this lane's ray; the list is the same for all lanes (read once, through LDS
-// broadcasts, into SGPRs) and so are the faces, which come through the scalar cache as in mesh_collide_packet.  f: the ray's
-// float32 origin in the bundle's frame, (o + d * T) - mesh centre.  Must be entered by the lanes of a wave together.
-// minima: the distances are suffix minima (beam_suffix_min), so the first entry beyond every lane's hit ends the search.
-RT_DEV void beam_test(const DScene& sc, const DMesh& m, const Ray& r, const FastRay& f, float dx, float dy, float dz, float err_r, float err_d,
-                      double T, const int32_t* cand, int n, bool minima, double tmin, BeamHit& bh, VisitCounts& cnt) {
-    const double* pos = sc.prim_pos + m.prim_off * 9;
-    const Tri32* tri32 = sc.prim_tri32 + m.prim_off;
-    for (int c = 0; c < n; c++) {
-        uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane(cand[3 * c + 2]);
-        if (mask == 0) continue;  // no face of this leaf can be hit by any ray of the bundle
-        const float tb = __int_as_float(__builtin_amdgcn_readfirstlane(cand[3 * c + 1]));
-        if (__builtin_amdgcn_ballot_w64(tb <= bh.tmax32) == 0) {  // the leaf begins beyond every lane's hit
-            if (minima) break;
-            continue;
-        }
-        const int32_t first = (int32_t)((uint32_t)~__builtin_amdgcn_readfirstlane(cand[3 * c]) >> RT_BEAM_LEAF_BITS);
-        RT_STAT(2, 1);
-        for (; mask != 0; mask &= mask - 1) {
-            const int32_t face = first + (__builtin_ffs((int)mask) - 1);
-            const Tri32 t32 = load_tri32_scalar(tri32, face);
-            const bool maybe = tb <= bh.tmax32 && !tri32_rejects(t32, f, dx, dy, dz, err_r, err_d);
-            RT_STAT(3, 1);
-            if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
-            RT_STAT(4, 1);
-            if (maybe) {
-                cnt.prims++;
-                const RT_CONST_AS double* p = (const RT_CONST_AS double*)(pos + (int64_t)face * 9);
-                const V3 p0 = mk(p[0], p[1], p[2]), p1 = mk(p[3], p[4], p[5]), p2 = mk(p[6], p[7], p[8]);
-                double t, u, v;
-                // equal distances: the face latest in leaf order wins, as in mesh_collide_packet
-                if (mt_core(r, p0, p1, p2, 1e-8, tmin, bh.t, t, u, v) && !(bh.hit && t == bh.t && face < bh.prim)) {
-                    bh.hit = true;
-                    bh.tmax32 = up32(t - T);
-                    bh.prim = face;
-                    bh.t = t; bh.u = u; bh.v = v;
-                }
-            }
-        }
-    }
-}
 
 }  // namespace rt

@@ -55,10 +55,8 @@ struct RayStripeCounts {
 };
 
 // cam and q point to DEVICE copies of the structs
-// beam: the caller has an orthographic camera and wants the pixel-beam kernel; used when the scene and the pass allow it
-// (fast mode, a single untransformed mesh, 64 lanes per pixel, at most beam_pixels_max() pixels per item).
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
-                    double* film, hipStream_t s, bool beam = false);
+                    double* film, hipStream_t s);
 int beam_pixels_max();
 // The pixel-beam kernel (k_beam) and the pre-pass that fills its tables for a camera direction (dev_beam.h).  launch_beam
 // returns false when the pass cannot run on it (fewer than 64 lanes per pixel, larger items, one sample per pixel).

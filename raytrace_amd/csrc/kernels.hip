@@ -692,12 +692,7 @@ RT_DEV int trace_one(const DScene& sc, const Ray& r, V3 rad, SceneHit& h, V3& em
 
 // One work item of a primary pass: pass.block_px consecutive pixels (sub-block `sub`) of tile v, all samples of the
 // pass, traced by one wave (lane p of it).  See k_primary for how lanes are dealt to samples and pixels.
-// BEAM (fast mode, one untransformed mesh, orthographic camera, all 64 lanes on one pixel, at most kBeamPixels pixels per
-// item): the tree is walked once per pixel for the bundle of its samples instead of once per round of 64 samples, see
-// "pixel beams" in dev_bvh.h.  Dynamic LDS then holds the walking lanes' stacks (lane j: 2 * cap dwords at j * 2 * cap),
-// the running sums, and at pass.beam_offset the lists (kBeamPixels x kBeamCands triples), the walks' states and 16 dwords
-// for beam_cull_item.
-template <int MODE, bool MESH_ONLY, bool SHADE, bool BEAM, bool NO_MESH>
+template <int MODE, bool MESH_ONLY, bool SHADE, bool NO_MESH>
 RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const Queues& q, double* __restrict__ film, long long v,
                          uint32_t sub, int p, LdsStack ls, double* acc_lds, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, uint32_t& rot,
                          VisitCounts& vc) {
@@ -711,54 +706,6 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
     const int tile_x = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8;
     const int tile_y = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8;
     const double inv_dx = 1.0 / (double)pass.dx, inv_dy = 1.0 / (double)pass.dy;  // for div_by: the divisions of render.go:202-210
-    int32_t* const beam_cand = dyn_lds + pass.beam_offset;
-    int32_t* const beam_state = beam_cand + kBeamPixels * kBeamCands * 3;
-    if (BEAM) {
-#ifdef RT_VISIT_STATS
-        const long long beam_t0 = clock64();
-        uint32_t beam_steps = 0;
-#define RT_BEAM_STEPS , beam_steps
-#else
-#define RT_BEAM_STEPS
-#endif
-        // lane j walks the bundle of pixel j of the item: the first instalment of its list, and whether there is more
-        if (p < pass.block_px) {
-            int32_t* const st = beam_state + p * kBeamStateDwords;
-            const int pix = (int)sub * pass.block_px + p;
-            const int lx = tile_x + (pix & 7), ly = tile_y + (pix >> 3);
-            const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);
-            int32_t found = 0;
-            if (lx < pass.dx && ly < pass.local_rows && row < pass.dy) {
-                const DMesh& m = sc.meshes[sc.nodes[0].index];
-                if (beam_setup(cam, pass.dx, pass.dy, m, lx, pass.dy - 1 - row, st)) {
-                    found = beam_fill(sc.fast_nodes + m.beam_off, st, dyn_lds + p * 2 * ls.cap, ls.cap, beam_cand + p * kBeamCands * 3, vc.overflow RT_BEAM_STEPS);
-                    if (st[12] != kFastEmpty) found |= 0x100;  // the list goes on: this pixel's rounds walk it in instalments
-                }
-            }
-            st[15] = found;
-#ifdef RT_VISIT_STATS
-            atomicAdd(&g_packet_stats[0], 1ull);                                  // pixels whose bundle was walked
-            atomicAdd(&g_packet_stats[1], (unsigned long long)beam_steps);        // inner nodes of those walks
-            atomicAdd(&g_packet_stats[6], (unsigned long long)(found & 0xff));    // leaves listed (first instalment)
-            if (found & 0x100) atomicAdd(&g_packet_stats[5], 1ull);               // pixels whose list goes on
-#endif
-        }
-#ifdef RT_VISIT_STATS
-        RT_STAT(8, clock64() - beam_t0);
-#endif
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        {
-            const DMesh& m = sc.meshes[sc.nodes[0].index];
-            beam_cull_item(sc.prim_tri32 + m.prim_off, m.radius, beam_state, beam_cand, beam_state + kBeamPixels * kBeamStateDwords, pass.block_px, p);
-        }
-        if (p < pass.block_px) {
-            const int32_t found = beam_state[p * kBeamStateDwords + 15];
-            if (!(found & 0x100)) beam_suffix_min(beam_cand + p * kBeamCands * 3, found & 0xff);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
     for (int pb = 0; pb < pass.block_px; pb += px_per_iter) {
         const int pix = (int)sub * pass.block_px + pb + my_px;  // index of this lane's pixel inside the tile, row-major
         const int lx = tile_x + (pix & 7);
@@ -771,25 +718,6 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
         // The pixel's running sum lives in LDS (acc_lds[c * 64], this lane's column), not in registers: it is touched once
         // per sample and would otherwise be carried, or spilled, across every walk.
         acc_lds[0] = 0; acc_lds[64] = 0; acc_lds[128] = 0;
-        // BEAM: this pixel's list (wave-uniform values: every lane reads the same LDS words)
-        int32_t* const px_state = beam_state + pb * kBeamStateDwords;
-        int32_t* const px_cand = beam_cand + pb * kBeamCands * 3;
-        int beam_first = 0;
-        bool beam_long = false;
-        double beam_T = 0;
-        if (BEAM) {
-            const int32_t found = __builtin_amdgcn_readfirstlane(px_state[15]);
-            beam_first = found & 0xff;
-            beam_long = (found & 0x100) != 0;
-            beam_T = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[11]) << 32) |
-                                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[10])));
-            if (pass.cull_pixels && found == 0) {  // nothing listed: no ray through this pixel can hit, whatever its jitter
-                n_total += (uint32_t)pass.sample_count;
-                n_left += (uint32_t)pass.sample_count;
-                n_culled += (uint32_t)pass.sample_count;
-                continue;
-            }
-        }
         for (int round = 0; round < rounds; round++) {
 #ifdef RT_VISIT_STATS
             const long long round_t0 = clock64();
@@ -817,12 +745,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                     fs = div_by((double)lxv + rng.float64(), (double)pass.dx, inv_dx);
                     ft = div_by((double)yv + rng.float64(), (double)pass.dy, inv_dy);
                 }
-                if (BEAM) {  // the camera is orthographic (camera_orthographic.go:24-46); its direction is the same for every lane
-                    r.o = (ld3(cam.from) + ld3(cam.u) * (cam.fov_w * (fs - 0.5))) + ld3(cam.v) * (cam.fov_h * (ft - 0.5));
-                    r.d = ld3(cam.dir);
-                } else {
-                    r = camera_cast(cam, fs, ft, rng);
-                }
+                r = camera_cast(cam, fs, ft, rng);
 #ifdef RT_VISIT_STATS
                 RT_STAT(13, clock64() - round_t0);
 #endif
@@ -831,71 +754,11 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
                 ps.sample = (uint32_t)s;
                 ps.path = 1;
                 ps.depth_n = rng.n;
-                if (!BEAM) {
-                    V3 em;
-                    const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST, NO_MESH>(sc, r, mk(1, 1, 1), h, em, ls, vc);
-                    if (what == 1) { acc_lds[0] += em.x; acc_lds[64] += em.y; acc_lds[128] += em.z; }
-                    want = what == 2;
-                    missed = what == 0;
-                }
-            }
-            if (BEAM) {
-                const DMesh& m = sc.meshes[sc.nodes[0].index];
-                const bool sound = traced && !(bad3(r.o) || bad3(r.d));  // render.go:147-150
-                BeamHit bh{false, __builtin_inff(), 0, kMaxFloat, 0, 0};
-                FastRay f{};
-                // every ray of an orthographic camera has the camera's direction (camera_orthographic.go:44)
-                const float dxf = (float)cam.dir[0], dyf = (float)cam.dir[1], dzf = (float)cam.dir[2];
-                const float err_d = kErr * sqrtf(dxf * dxf + dyf * dyf + dzf * dzf), err_r = err_d * m.radius;
-                if (sound) {
-                    const V3 ol = (r.o + r.d * beam_T) - ld3(m.center);
-                    f.ox = (float)ol.x; f.oy = (float)ol.y; f.oz = (float)ol.z;
-                }
-                bool walking = beam_long;  // wave-uniform
-                if (walking && p == pb) beam_setup(cam, pass.dx, pass.dy, m, lx, y, px_state);  // this round's walk starts over
-#ifdef RT_VISIT_STATS
-                const long long faces_t0 = clock64();
-#endif
-                do {
-                    int n = beam_first;
-                    if (walking) {
-#ifdef RT_VISIT_STATS
-                        uint32_t again = 0;
-                        if (p == pb) px_state[15] = beam_fill(sc.fast_nodes + m.beam_off, px_state, dyn_lds + pb * 2 * ls.cap, ls.cap, px_cand, vc.overflow, again);
-                        RT_STAT(7, 1);  // instalments walked inside rounds
-#else
-                        if (p == pb) px_state[15] = beam_fill(sc.fast_nodes + m.beam_off, px_state, dyn_lds + pb * 2 * ls.cap, ls.cap, px_cand, vc.overflow);
-#endif
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        n = __builtin_amdgcn_readfirstlane(px_state[15]);
-                    }
-                    if (sound && n > 0) beam_test(sc, m, r, f, dxf, dyf, dzf, err_r, err_d, beam_T, px_cand, n, !beam_long, kEps, bh, vc);
-                    if (walking) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        walking = __builtin_amdgcn_readfirstlane(px_state[12]) != kFastEmpty;
-                    }
-                } while (walking);
-#ifdef RT_VISIT_STATS
-                RT_STAT(12, clock64() - faces_t0);
-#endif
-                if (sound) {
-                    if (bh.hit) {
-                        h.c.t = bh.t; h.c.u = bh.u; h.c.v = bh.v;
-                        h.node = 0;
-                        h.leaf = bh.prim;
-                        h.rec_leaf = bh.prim;
-                        h.prim = sc.prim_face[m.prim_off + bh.prim];
-                    } else {
-                        h.leaf = -1;
-                    }
-                    V3 em;
-                    const int what = after_closest(sc, r, mk(1, 1, 1), bh.hit, h, em);
-                    if (what == 1) { acc_lds[0] += em.x; acc_lds[64] += em.y; acc_lds[128] += em.z; }
-                    want = what == 2;
-                    missed = what == 0;
-                }
+                V3 em;
+                const int what = trace_one<MODE, MESH_ONLY, MODE == RT_MODE_FAST, NO_MESH>(sc, r, mk(1, 1, 1), h, em, ls, vc);
+                if (what == 1) { acc_lds[0] += em.x; acc_lds[64] += em.y; acc_lds[128] += em.z; }
+                want = what == 2;
+                missed = what == 0;
             }
             n_left += (uint32_t)__popcll(__ballot(missed));
             if (SHADE) {
@@ -942,7 +805,7 @@ RT_DEV void primary_item(const DScene& sc, const DCamera& cam, const PassDesc& p
 // queues exhausted.
 // SHADE = false: the host has checked that every material only emits, so no hit ever needs Material.Resolve and
 // its code (and registers) is left out.
-template <int MODE, bool MESH_ONLY, bool SHADE, bool BEAM = false, bool NO_MESH = false>
+template <int MODE, bool MESH_ONLY, bool SHADE, bool NO_MESH = false>
 __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY ? (SHADE ? RT_PACKET_SHADE_WAVES : RT_PACKET_WAVES) : (NO_MESH ? (SHADE ? RT_SHAPES_SHADE_WAVES : RT_SHAPES_WAVES) : (SHADE ? RT_FAST_SHADE_WAVES : RT_FAST_WAVES))) : 2) k_primary(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, const Queues* __restrict__ qp, double* __restrict__ film) {
     // The camera and the queue descriptors are read through pointers where they are used: as by-value arguments
     // their ~100 dwords would sit in SGPRs for the whole kernel and push other scalars out into VGPR lanes.
@@ -990,7 +853,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
         if (v < 0) break;
         const long long t_start = pass.cost ? clock64() : 0;
         sub = __shfl(sub, 0, 64);
-        primary_item<MODE, MESH_ONLY, SHADE, BEAM, NO_MESH>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
+        primary_item<MODE, MESH_ONLY, SHADE, NO_MESH>(sc, cam, pass, q, film, v, sub, p, LdsStack{dyn_lds + threadIdx.x, kTraceBlock, sc.stack_pairs},
                                              reinterpret_cast<double*>(dyn_lds + pass.acc_offset) + threadIdx.x, n_total, n_left, n_culled, rot, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
@@ -1011,7 +874,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
 // for the camera's direction (dev_beam.h).  The persistent single-wave workgroups and their per-XCD queues are
 // k_primary's.
 #ifndef RT_BEAM_WAVES
-#define RT_BEAM_WAVES 4
+#define RT_BEAM_WAVES 5  // measured on the 4K scan (items of 4 pixels, 12 compact faces): 4 waves 85.5 ms, 5 waves 78.5 ms, 6 waves (8 compact faces) 90.3 ms
 #endif
 
 // The tables of dev_beam.h for direction (dx, dy, dz): one thread per face, leaf order.
@@ -1066,7 +929,7 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
 
 // One work item: pass.block_px (at most kBeamPixels) consecutive pixels of tile v, all samples of the pass.  Dynamic LDS:
 // the walking lanes' stacks (lane j: 2 * cap dwords at j * 2 * cap), then at pass.beam_offset the lists (kBeamPixels x
-// kBeamCands triples), the walks' states and 16 dwords for beam_cull_item32.
+// kBeamCands triples), the walks' states, kBeamCullDwords for beam_cull_item32 and the pixels' compact face arrays.
 template <bool IMG>
 RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const BeamTables& bt, double* __restrict__ film, long long v,
                       uint32_t sub, int p, int cap, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, VisitCounts& vc) {
@@ -1079,6 +942,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     const double inv_dx = 1.0 / (double)pass.dx, inv_dy = 1.0 / (double)pass.dy;  // for div_by: the divisions of render.go:202-210
     int32_t* const beam_cand = dyn_lds + pass.beam_offset;
     int32_t* const beam_state = beam_cand + kBeamPixels * kBeamCands * 3;
+    int32_t* const beam_compact = beam_state + kBeamPixels * kBeamStateDwords + kBeamCullDwords;
     const DMesh& m = sc.meshes[sc.nodes[0].index];
     const FastNode* const tree = sc.fast_nodes + m.beam_off;
     // lane j walks the bundle of pixel j of the item: the first instalment of its list, and whether there is more
@@ -1104,13 +968,14 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    beam_cull_item32(bt.f32, beam_state, beam_cand, beam_state + kBeamPixels * kBeamStateDwords, pass.block_px, p);
+    beam_cull_item32(bt.f32, beam_state, beam_cand, beam_state + kBeamPixels * kBeamStateDwords, beam_compact, pass.block_px, p);
     if (p < pass.block_px) {
         const int32_t found = beam_state[p * kBeamStateDwords + 15];
         if (!(found & 0x100)) beam_suffix_min(beam_cand + p * kBeamCands * 3, found & 0xff);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    beam_patch_distances(beam_state, beam_cand, beam_compact, pass.block_px, p);
 
     // what every hit of the item samples (wave-uniform: scalar loads)
     const rt_material& mat = sc.materials[sc.nodes[0].material];
@@ -1138,6 +1003,9 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         const int32_t found = __builtin_amdgcn_readfirstlane(px_state[15]);
         const int beam_first = found & 0xff;
         const bool beam_long = (found & 0x100) != 0;
+        const int n_compact = __builtin_amdgcn_readfirstlane(px_state[25]);
+        const bool use_compact = !beam_long && n_compact <= kBeamFacesMax;  // else: the leaf list, face data from memory
+        const int32_t* const px_compact = beam_compact + pb * kBeamFacesMax * kBeamFaceDwords;
         const double beam_T = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[11]) << 32) |
                                                                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[10])));
         if (pass.cull_pixels && found == 0) {  // nothing listed: no ray through this pixel can hit, whatever its jitter
@@ -1176,7 +1044,8 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
 #ifdef RT_VISIT_STATS
             const long long faces_t0 = clock64();
 #endif
-            do {
+            if (use_compact) beam_test_compact(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, bh);
+            else do {
                 int n = beam_first;
                 if (walking) {
 #ifdef RT_VISIT_STATS
@@ -2012,7 +1881,7 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     PassDesc pd = pass;
     pd.acc_offset = 0;
     pd.beam_offset = (int32_t)(lds / sizeof(int32_t));
-    lds += ((size_t)kBeamPixels * (kBeamCands * 3 + kBeamStateDwords) + 16) * sizeof(int32_t);
+    lds += ((size_t)kBeamPixels * (kBeamCands * 3 + kBeamStateDwords + kBeamFacesMax * kBeamFaceDwords) + kBeamCullDwords) * sizeof(int32_t);
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);
@@ -2025,22 +1894,17 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
 }
 
 void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, const Queues* q, int mode, bool mesh_only, bool shade,
-                    double* film, hipStream_t s, bool beam) {
+                    double* film, hipStream_t s) {
     if (pass.n_pixels <= 0) return;
-    // not with Material.Resolve in the kernel: that variant spills 480 B per lane and measured 9 % slower than the packet walk
-    beam = beam && !shade && mode == RT_MODE_FAST && mesh_only && sc.n_nodes == 1 && pass.log2_s == 6 && pass.block_px <= kBeamPixels;
     size_t lds = stack_bytes(sc, mode);
     // wave-packet traversal: one distance per lane and level, one reference per level
     if (mode == RT_MODE_FAST) lds = (size_t)sc.stack_pairs * (kTraceBlock + kTraceBlock / 64) * sizeof(int32_t);
-    // pixel beams: the stacks of the kBeamPixels walking lanes, a (reference, distance) pair per level each
-    if (beam) lds = (size_t)kBeamPixels * 2 * sc.stack_pairs * sizeof(int32_t);
     // behind the stack: the running sums of the pixels being traced, three float64 per lane
     lds = (lds + 7) & ~(size_t)7;
     PassDesc pd = pass;
     pd.acc_offset = (int32_t)(lds / sizeof(int32_t));
     lds += (size_t)3 * kTraceBlock * sizeof(double);
-    pd.beam_offset = (int32_t)(lds / sizeof(int32_t));
-    if (beam) lds += ((size_t)kBeamPixels * (kBeamCands * 3 + kBeamStateDwords) + 16) * sizeof(int32_t);
+    pd.beam_offset = 0;
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);
@@ -2051,10 +1915,9 @@ void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, 
     };
     auto pick = [&](auto mode_tag) {
         constexpr int M = decltype(mode_tag)::value;
-        if (M == RT_MODE_FAST && beam) go(k_primary<RT_MODE_FAST, true, false, true>);
-        else if (mesh_only) { if (shade) go(k_primary<M, true, true>); else go(k_primary<M, true, false>); }
+        if (mesh_only) { if (shade) go(k_primary<M, true, true>); else go(k_primary<M, true, false>); }
         else if (M == RT_MODE_FAST && sc.n_meshes == 0) {  // no tree to walk: the walk's code and registers are left out
-            if (shade) go(k_primary<RT_MODE_FAST, false, true, false, true>); else go(k_primary<RT_MODE_FAST, false, false, false, true>);
+            if (shade) go(k_primary<RT_MODE_FAST, false, true, true>); else go(k_primary<RT_MODE_FAST, false, false, true>);
         }
         else           { if (shade) go(k_primary<M, false, true>); else go(k_primary<M, false, false>); }
     };

@@ -605,9 +605,9 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     int64_t item_rays = 256;   // measured 64 / 128 / 256 / 512, Grays/s: scan-lit 5.54 / 5.53 / 5.44 / 5.20, material 7.31 / 7.30 / 7.28 / 7.18, teapot 5.43 / 5.50 / 5.54 / 5.56, charuco orbit 610 / 670 / 681 / 662 frames/s
     if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
     // Pixel beams (one tree walk per pixel instead of one per 64 samples, see dev_bvh.h): parallel rays through one mesh.
-    const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC && !getenv("RT_NO_BEAM");
-    const bool beam_tables = beam && rep.beam_faces > 0 && !getenv("RT_OLD_BEAM");
-    if (beam_tables) {
+    const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC &&
+                      rep.beam_faces > 0 && o->rays_per_pixel > 1 && !getenv("RT_NO_BEAM");
+    if (beam) {
         // the tables belong to a direction: every ray of the frame has the camera's (camera_orthographic.go:44)
         if (!rep.beam_dir_valid || std::memcmp(rep.beam_dir, cam.dir, sizeof(rep.beam_dir)) != 0) {
             launch_beam_prepare(rep.dev, rep.beam_faces, cam.dir, const_cast<BeamFace32*>(rep.beam.f32), const_cast<BeamFace64*>(rep.beam.f64),
@@ -698,8 +698,8 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 HIP_TRY(events.next(&ev));
                 HIP_TRY(hipEventRecord(ev->a, stream));
             }
-            if (!(beam_tables && launch_beam(rep.dev, w.d_camera, pass, q.counters, rep.beam, film, stream)))
-                launch_primary(rep.dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream, beam);
+            if (!(beam && launch_beam(rep.dev, w.d_camera, pass, q.counters, rep.beam, film, stream)))
+                launch_primary(rep.dev, w.d_camera, pass, w.d_queues, o->mode, sc->mesh_only, !sc->all_terminal, film, stream);
             if (pass.order) culled_rays += w.culled_pixels * (uint64_t)s_count;  // tiles the schedule leaves out: nothing to trace
             if (timed) HIP_TRY(hipEventRecord(ev->b, stream));
             HIP_TRY(hipGetLastError());
