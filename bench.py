@@ -344,11 +344,11 @@ def main():
             "ok": ok, "pixels": int(mask.sum()), "samples_per_pixel": int(n_cmp), "max_rel_diff_of_sums": float(err.max()),
             "frac_rel_diff_gt_1e-12": float((err > 1e-12).mean()), "nonzero_fraction": float((want > 0).any(axis=1).mean()),
             "film": "the timed steps' own film" if same_film else "an extra render of the oracle's sample range (untimed)",
-            "kernel": "k_primary<beam>" if n_cmp >= 64 else "k_primary (packet walk: fewer than 64 samples per pass)",
+            "kernel": "k_beam" if n_cmp >= 64 else "k_primary (packet walk: fewer than 64 samples per pass)",
             "bar": "radiance sums per pixel and channel equal to 1e-9 relative (same samples, same float64 face arithmetic; only the "
                    "order of the additions differs)",
         }
-    # Roofline of the dominant kernel, k_primary<beam> (camera ray + the pixel's face list + emitter shading, one launch per
+    # Roofline of the dominant kernel, k_beam (camera ray + the pixel's face list + emitter shading, one launch per
     # step), over rank 0's launches of the timed steps; launch time = the library's HIP-event time around the launches on
     # their own stream.  The kernel is bound by vector instruction issue, not by HBM (the scene sits in L2 and the
     # memory-side cache), so the roofline is the chip's vector issue rate and what is priced are the instructions the work
@@ -379,20 +379,20 @@ def main():
             achieved = floor / 64.0 * my_rays / max(my_secs, 1e-12) / 1e9
             result["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": achieved / VALU_PEAK_GINST,
-                "traffic": stored.get("k_primary_hbm_bytes_per_launch") if stored else None,
-                "kernel": "k_primary<fast, mesh-only, beam>", "avg_launch_ms": 1e3 * avg_launch_s, "rays_per_launch": my_rays / max(float(trav_launches), 1.0),
+                "traffic": stored.get("hbm_bytes_per_launch") if stored else None,
+                "kernel": "k_beam<image texture>", "avg_launch_ms": 1e3 * avg_launch_s, "rays_per_launch": my_rays / max(float(trav_launches), 1.0),
                 "needed_valu_insts_per_64_rays": floor, "hit_fraction": hit_fraction,
                 "floor_by_stage": [{"stage": st, "paid_by": who, "wave_insts": n} for st, who, n, _ in VALU_FLOOR],
                 "peak_is": f"{SIMDS} SIMDs x {PEAK_CLOCK_HZ / 1e9} GHz / 4 cycles per wave-wide float64 or integer vector instruction",
                 "note": "achieved = vector instructions the work needs (floor_by_stage, weighted by the fraction of rays that pay each stage) x "
                         "rays per second measured in this run; the instructions the kernel actually executes are in valu_counters",
             }
-        if stored and "k_primary_valu_busy" in stored:
+        if stored and "valu_busy" in stored:
             result["valu_counters"] = {
-                "valu_busy": stored["k_primary_valu_busy"], "lanes_enabled": stored.get("k_primary_lanes_enabled"),
+                "valu_busy": stored["valu_busy"], "lanes_enabled": stored.get("lanes_enabled"),
                 "valu_insts_per_64_rays": stored.get("valu_insts_per_wave_of_64_rays"),
                 "floor_over_executed": (floor / stored["valu_insts_per_wave_of_64_rays"]) if floor and stored.get("valu_insts_per_wave_of_64_rays") else None,
-                "hbm_counter_frac": (stored["k_primary_hbm_bytes_per_launch"] / avg_launch_s / 1e9 / HBM_PEAK_GBS) if stored.get("k_primary_hbm_bytes_per_launch") else None,
+                "hbm_counter_frac": (stored["hbm_bytes_per_launch"] / avg_launch_s / 1e9 / HBM_PEAK_GBS) if stored.get("hbm_bytes_per_launch") else None,
                 "csrc_sha16": stored.get("csrc_sha16"),
                 "source": "STORED values of rocprofv3 --pmc passes over this command at the same device sources (profiles/counters.json; "
                           "tools/profile_pmc.sh, tools/make_counters.py), not measured in this run",

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes profiles/counters.json from the passes of tools/profile_pmc.sh over a bench.py run.
 
-Per k_primary launch of the timed steps:
+Per launch of the dominant kernel (k_beam) in the timed steps:
   HBM-side bytes = 2 * FETCH_SIZE + WRITE_SIZE   (both in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes)
   VALU busy      = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
   lanes enabled  = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)
@@ -20,7 +20,7 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/counters.json"
 rays = float(sys.argv[3]) if len(sys.argv) > 3 else 8493465600.0
 TIMED = int(os.environ.get("TIMED_LAUNCHES", "4"))  # the last launches of the run are bench.py's timed steps
-KERNEL = os.environ.get("PMC_KERNEL", "k_primary")
+KERNEL = os.environ.get("PMC_KERNEL", "k_beam<")  # k_beam<...>, not k_beam_prepare
 
 
 def per_launch(group, counter):
@@ -42,12 +42,12 @@ insts, gui = per_launch("sq1", "SQ_INSTS_VALU"), per_launch("grbm", "GRBM_GUI_AC
 res = {
     "csrc_sha16": bench.source_hash(),
     "kernel": KERNEL, "timed_launches_averaged": TIMED, "rays_per_launch": rays,
-    "k_primary_hbm_bytes_per_launch": (2.0 * f + w) * 1024 if f is not None and w is not None else None,
+    "hbm_bytes_per_launch": (2.0 * f + w) * 1024 if f is not None and w is not None else None,
     "fetch_size_kib_per_launch_raw": f, "write_size_kib_per_launch_raw": w,
     "kernel_cycles": gui / 8 if gui else None,
-    "k_primary_valu_busy": 4.0 * act / (1024.0 * gui / 8.0) if act and gui else None,
-    "k_primary_lanes_enabled": thr / (64.0 * act) if act and thr else None,
-    "k_primary_valu_insts_per_ray": insts / rays if insts else None,
+    "valu_busy": 4.0 * act / (1024.0 * gui / 8.0) if act and gui else None,
+    "lanes_enabled": thr / (64.0 * act) if act and thr else None,
+    "valu_insts_per_ray": insts / rays if insts else None,
     "valu_insts_per_wave_of_64_rays": insts / (rays / 64.0) if insts else None,
     "method": "rocprofv3 --pmc, one counter group per run of bench.py (tools/profile_pmc.sh); FETCH_SIZE doubled for gfx950; "
               "means over the launches of the timed steps",
