@@ -9,6 +9,12 @@
 // are the reference's numbers bit for bit.  The conservative float32 pre-test is prepared the same way: with
 // U = s . (d x e2) and V = s . (e1 x d) the face can be rejected when U < -eu, V < -ev or U + V > |a| + eu + ev + ea (signs
 // mirrored for a < 0; margins as in tri32_rejects), which per ray is a subtraction, two dot products and three compares.
+//
+// Rays from ONE point (PinholeCamera, camera_pinhole.go:20-34; FocusableCamera with no aperture, camera_focusable.go:26-63)
+// share the other half: s = o - p0, q = s x edge1 and edge2 . q are the same for every ray, and what a ray computes is
+//   h = d x edge2, a = edge1 . h, f = 1 / a, u = f (s . h), v = f (d . q), t = f (edge2 . q).
+// The tables have the same shape with other contents (BeamFace64: s, edge1, edge2, q, edge2 . q; BeamFace32: the vectors
+// e2 x s, s x e1, e2 x e1, whose products with the direction are U, V and a, and the margins eu, ev, ea).  PYR selects them.
 #pragma once
 
 #include "dev_bvh.h"
@@ -48,6 +54,32 @@ RT_DEV bool face32_rejects_bundle(const BeamFace32& t, float ox, float oy, float
     return us + dU < t.neg_eu || vs + dV < t.neg_ev || (us - dU) + (vs - dV) > t.lim;
 }
 
+// Rays from one point: one ray's direction against a face prepared for that point.  The table's fields hold
+// A = e2 x s (p0), Q = s x e1 (h), N = e2 x e1 (g) and eu, ev, ea (neg_eu, neg_ev, lim).
+RT_DEV bool face32_rejects_dir(const BeamFace32& t, float dx, float dy, float dz) {
+#pragma clang fp contract(fast)
+    const float U = dx * t.p0[0] + dy * t.p0[1] + dz * t.p0[2];
+    const float V = dx * t.h[0] + dy * t.h[1] + dz * t.h[2];
+    const float a = dx * t.g[0] + dy * t.g[1] + dz * t.g[2];
+    const float eu = t.neg_eu, ev = t.neg_ev, ea = t.lim, aa = fabsf(a);
+    if (!(aa > ea)) return false;  // sign of a uncertain (grazing or degenerate): let float64 decide
+    const float us = a < 0 ? -U : U, vs = a < 0 ? -V : V;
+    return us < -eu || vs < -ev || us + vs > aa + eu + ev + ea;
+}
+
+// The same for every direction in the box (cx, cy, cz) +- (ex, ey, ez): U, V and a are linear in the direction.
+RT_DEV bool face32_rejects_dirs(const BeamFace32& t, float cx, float cy, float cz, float ex, float ey, float ez) {
+#pragma clang fp contract(fast)
+    const float slack = 1.0f + 1.0f / 65536.0f;  // the bounds themselves are rounded
+    const float U = cx * t.p0[0] + cy * t.p0[1] + cz * t.p0[2], dU = (ex * fabsf(t.p0[0]) + ey * fabsf(t.p0[1]) + ez * fabsf(t.p0[2])) * slack;
+    const float V = cx * t.h[0] + cy * t.h[1] + cz * t.h[2], dV = (ex * fabsf(t.h[0]) + ey * fabsf(t.h[1]) + ez * fabsf(t.h[2])) * slack;
+    const float a = cx * t.g[0] + cy * t.g[1] + cz * t.g[2], da = (ex * fabsf(t.g[0]) + ey * fabsf(t.g[1]) + ez * fabsf(t.g[2])) * slack;
+    const float eu = t.neg_eu, ev = t.neg_ev, ea = t.lim, aa = fabsf(a);
+    if (!(aa - da > ea)) return false;  // the sign of a is not the same, for certain, over the whole bundle
+    const float us = a < 0 ? -U : U, vs = a < 0 ? -V : V;
+    return us + dU < -eu || vs + dV < -ev || (us - dU) + (vs - dV) > (aa + da) + eu + ev + ea;
+}
+
 // What a pixel's rounds test, when it is short enough: the faces that survive beam_cull_item32, in list order, each with its
 // prepared float32 form in LDS -- kBeamFaceDwords dwords: BeamFace32 (12), the entry distance of its leaf (suffix minimum), its
 // position in leaf order.  A round then reads no memory until a face passes the pre-test.  A pixel with more survivors
@@ -63,6 +95,7 @@ constexpr int kBeamCullDwords = 32;  // beam_cull_item32's own LDS: prefix sums 
 // face against the bundle of the leaf's pixel; the survivors become the leaf's mask and are appended, in list order, to the
 // pixel's compact array (entry 12 holds the position of the face's leaf in the list until beam_patch_distances has run).
 // beam_state[j * kBeamStateDwords + 25] receives the number of survivors of pixel j.  Must be entered by all 64 lanes.
+template <bool PYR>
 RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32_t* beam_cand, int32_t* prefix, int32_t* compact, int n_px, int lane) {
     int len = 0;
     if (lane < n_px) {
@@ -102,8 +135,10 @@ RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32
                 const int32_t* st = beam_state + j * kBeamStateDwords;
                 face = (int32_t)(code >> RT_BEAM_LEAF_BITS) + q;
                 t = faces[face];
-                keep = !face32_rejects_bundle(t, __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]), __int_as_float(st[19]),
-                                              __int_as_float(st[20]), __int_as_float(st[21]));
+                if (PYR) keep = !face32_rejects_dirs(t, __int_as_float(st[19]), __int_as_float(st[20]), __int_as_float(st[21]), __int_as_float(st[22]),
+                                                     __int_as_float(st[23]), __int_as_float(st[24]));
+                else keep = !face32_rejects_bundle(t, __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]), __int_as_float(st[19]),
+                                                   __int_as_float(st[20]), __int_as_float(st[21]));
             }
         }
         const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
@@ -156,35 +191,61 @@ RT_DEV void beam_patch_distances(const int32_t* beam_state, const int32_t* beam_
     __builtin_amdgcn_wave_barrier();
 }
 
-// One prepared face (float64) against this lane's ray: shape_mesh.go:110-124 with edge1, edge2, h, f as prepared; keeps the
-// closest hit in bh.  Entered by all lanes of the wave; `maybe` = this lane's ray passed the pre-test.
+// One prepared face (float64) against this lane's ray: shape_mesh.go:99-124 with what the bundle's rays share taken from the
+// table; keeps the closest hit in bh.  Entered by all lanes of the wave; `maybe` = this lane's ray passed the pre-test.
+// o, d: the ray (PYR: o is not read, the table holds s = o - p0; else d is the same for every lane).
+template <bool PYR>
 RT_DEV void beam_face64(const BeamTables& bt, int32_t face, V3 o, V3 d, double T, double tmin, bool maybe, BeamHit& bh) {
     const RT_CONST_AS double* p = (const RT_CONST_AS double*)(bt.f64 + face);
-    const double f = p[12];
-    // a face the reference rejects whatever the ray (shape_mesh.go:107-109): f is NaN, all bits of its exponent set
-    if (((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(__double_as_longlong(f) >> 32)) & 0x7ff00000u) == 0x7ff00000u) return;
-    if (maybe) {
-        const double e = 1e-8;
-        const V3 s = o - mk(p[0], p[1], p[2]);
-        const double u = f * dot(s, mk(p[9], p[10], p[11]));
-        if (!(u < -e || u > 1.0 + e)) {
-            const V3 q = cross(s, mk(p[3], p[4], p[5]));
-            const double v = f * dot(d, q);
-            if (!(v < -e || u + v > 1.0 + e)) {
-                const double t = f * dot(mk(p[6], p[7], p[8]), q);
-                // equal distances: the face latest in leaf order wins, as in mesh_collide_packet
-                if (!(t < tmin || t > bh.t) && !(bh.hit && t == bh.t && face < bh.prim)) {
-                    bh.hit = true;
-                    bh.tmax32 = up32(t - T);
-                    bh.prim = face;
-                    bh.t = t; bh.u = u; bh.v = v;
+    const double e = 1e-8;
+    double t = 0, u = 0, v = 0;
+    bool ok = false;
+    if (PYR) {
+        if (maybe) {
+            const V3 s = mk(p[0], p[1], p[2]), edge1 = mk(p[3], p[4], p[5]), edge2 = mk(p[6], p[7], p[8]), q = mk(p[9], p[10], p[11]);
+            const V3 h = cross(d, edge2);
+            const double a = dot(edge1, h);
+            if (!(a > -e && a < e)) {
+                const double f = 1 / a;
+                u = f * dot(s, h);
+                if (!(u < -e || u > 1.0 + e)) {
+                    v = f * dot(d, q);
+                    if (!(v < -e || u + v > 1.0 + e)) {
+                        t = f * p[12];
+                        ok = !(t < tmin || t > bh.t);
+                    }
+                }
+            }
+        }
+    } else {
+        const double f = p[12];
+        // a face the reference rejects whatever the ray (shape_mesh.go:107-109): f is NaN, all bits of its exponent set
+        if (((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(__double_as_longlong(f) >> 32)) & 0x7ff00000u) == 0x7ff00000u) return;
+        if (maybe) {
+            const V3 s = o - mk(p[0], p[1], p[2]);
+            u = f * dot(s, mk(p[9], p[10], p[11]));
+            if (!(u < -e || u > 1.0 + e)) {
+                const V3 q = cross(s, mk(p[3], p[4], p[5]));
+                v = f * dot(d, q);
+                if (!(v < -e || u + v > 1.0 + e)) {
+                    t = f * dot(mk(p[6], p[7], p[8]), q);
+                    ok = !(t < tmin || t > bh.t);
                 }
             }
         }
     }
+    // equal distances: the face latest in leaf order wins, as in mesh_collide_packet
+    if (ok && !(bh.hit && t == bh.t && face < bh.prim)) {
+        bh.hit = true;
+        bh.tmax32 = up32(t - T);
+        bh.prim = face;
+        bh.t = t; bh.u = u; bh.v = v;
+    }
 }
 
 // The n compact entries of a pixel against this lane's ray.  Must be entered by the lanes of a wave together.
+// (fx, fy, fz): the ray's origin in the bundle's float32 frame, or (PYR) its direction.
+template <bool PYR>
 RT_DEV void beam_test_compact(const BeamTables& bt, V3 o, V3 d, float fx, float fy, float fz, double T, const int32_t* compact, int n, double tmin,
                               bool sound, BeamHit& bh) {
     for (int i = 0; i < n; i++) {
@@ -197,17 +258,18 @@ RT_DEV void beam_test_compact(const BeamTables& bt, V3 o, V3 d, float fx, float 
         t.h[0] = __int_as_float(e[3]); t.h[1] = __int_as_float(e[4]); t.h[2] = __int_as_float(e[5]);
         t.g[0] = __int_as_float(e[6]); t.g[1] = __int_as_float(e[7]); t.g[2] = __int_as_float(e[8]);
         t.neg_eu = __int_as_float(e[9]); t.neg_ev = __int_as_float(e[10]); t.lim = __int_as_float(e[11]);
-        const bool maybe = live && !face32_rejects(t, fx, fy, fz);
+        const bool maybe = live && !(PYR ? face32_rejects_dir(t, fx, fy, fz) : face32_rejects(t, fx, fy, fz));
         RT_STAT(3, 1);
         if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
         RT_STAT(4, 1);
-        beam_face64(bt, __builtin_amdgcn_readfirstlane(e[13]), o, d, T, tmin, maybe, bh);
+        beam_face64<PYR>(bt, __builtin_amdgcn_readfirstlane(e[13]), o, d, T, tmin, maybe, bh);
     }
 }
 
 // The faces of n listed leaves (those their masks name) against this lane's ray: beam_test (dev_bvh.h) on the prepared
 // tables.  o: the ray's float64 origin; (fx, fy, fz): the same in the bundle's float32 frame; d: the camera's direction
 // (the same for every lane).  Must be entered by the lanes of a wave together.
+template <bool PYR>
 RT_DEV void beam_test_prepared(const BeamTables& bt, V3 o, V3 d, float fx, float fy, float fz, double T, const int32_t* cand, int n, bool minima,
                                double tmin, bool sound, BeamHit& bh) {
     for (int c = 0; c < n; c++) {
@@ -223,11 +285,11 @@ RT_DEV void beam_test_prepared(const BeamTables& bt, V3 o, V3 d, float fx, float
         for (; mask != 0; mask &= mask - 1) {
             const int32_t face = first + (__builtin_ffs((int)mask) - 1);
             const BeamFace32 t32 = load_face32_scalar(bt.f32, face);
-            const bool maybe = sound && tb <= bh.tmax32 && !face32_rejects(t32, fx, fy, fz);
+            const bool maybe = sound && tb <= bh.tmax32 && !(PYR ? face32_rejects_dir(t32, fx, fy, fz) : face32_rejects(t32, fx, fy, fz));
             RT_STAT(3, 1);
             if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
             RT_STAT(4, 1);
-            beam_face64(bt, face, o, d, T, tmin, maybe, bh);
+            beam_face64<PYR>(bt, face, o, d, T, tmin, maybe, bh);
         }
     }
 }

@@ -882,7 +882,7 @@ constexpr int kBeamPixels = RT_BEAM_PIXELS;      // pixels of a work item at mos
 // leaves listed per pixel at a time; a longer list is produced in instalments.  The lists of a wave's pixels live in LDS, which
 // caps the occupancy: measured on the 4K scan, pixels x leaves = 8 x 48: 59.5 Grays/s, 8 x 64: 63.0, 8 x 80: 54.0, 4 x 96: 63.9, 4 x 128: 63.6, 4 x 192: 54.2
 constexpr int kBeamCands = RT_BEAM_CANDS;
-constexpr int kBeamStateDwords = 32;
+constexpr int kBeamStateDwords = 48;
 constexpr int kBeamLeafFaces = 1 << RT_BEAM_LEAF_BITS;             // faces a leaf of the beams' tree holds at most
 constexpr uint32_t kBeamLeafMask = (1u << kBeamLeafFaces) - 1u;  // one bit per face of such a leaf
 
@@ -890,7 +890,10 @@ constexpr uint32_t kBeamLeafMask = (1u << kBeamLeafFaces) - 1u;  // one bit per 
 // p * i + a, of a max plane p * i + b), 6-8 i = 1 / direction, 9 t_lo (where the rays start, in the bundle's frame),
 // 10-11 T (float64: the frame starts at o + d * T), 12 cur, 13 sp, 14 entry distance of cur, 15 the caller's (length
 // of the list), 16-18 origin of the centre ray in that frame, 19-21 half-extent of the footprint (margins included),
-// 22-24 direction (float32).
+// 22-24 direction (float32).  25: survivors of the pixel's list (beam_cull_item32).
+// A pyramid of rays from one point (beam_setup_pyr) uses instead: 16-18 the point in the mesh frame, 19-21 the centre of the
+// box of its directions, 22-24 that box's half-widths, 26-43 per axis (1 / d_lo, 1 / d_hi and the four offsets of
+// beam_child_pyr), 44 bit k set = the directions' k-th components straddle zero, 45 factor from slab parameter to distance.
 //
 // Sets the walk of the pixel (lx, y) up.  False: the bundle misses the mesh.
 RT_DEV bool beam_setup(const DCamera& cam, int32_t dx_img, int32_t dy_img, const DMesh& m, int lx, int y, int32_t* state) {
@@ -941,17 +944,126 @@ RT_DEV bool beam_setup(const DCamera& cam, int32_t dx_img, int32_t dy_img, const
     return true;
 }
 
+// What beam_fill keeps in registers of a bundle, and its test of one child box: entry distance and whether the bundle can
+// reach the box at all.  Parallel rays (orthographic camera): the centre ray against the box grown by the footprint.
+struct BeamSlabsOrtho {
+    float ax, ay, az, bx, by, bz, ix, iy, iz, t_lo;
+    RT_DEV void load(const int32_t* state) {
+        ax = __int_as_float(state[0]); ay = __int_as_float(state[1]); az = __int_as_float(state[2]);
+        bx = __int_as_float(state[3]); by = __int_as_float(state[4]); bz = __int_as_float(state[5]);
+        ix = __int_as_float(state[6]); iy = __int_as_float(state[7]); iz = __int_as_float(state[8]);
+        t_lo = __int_as_float(state[9]);
+    }
+    RT_DEV bool child(const FastNode& n, int k, float& tnear) const {
+        const float x0 = __builtin_fmaf(n.b[k][0][0], ix, ax), x1 = __builtin_fmaf(n.b[k][0][1], ix, bx);
+        const float y0 = __builtin_fmaf(n.b[k][1][0], iy, ay), y1 = __builtin_fmaf(n.b[k][1][1], iy, by);
+        const float z0 = __builtin_fmaf(n.b[k][2][0], iz, az), z1 = __builtin_fmaf(n.b[k][2][1], iz, bz);
+        tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_lo));
+        const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        return tnear <= tfar;
+    }
+};
+
+// Rays from one point o whose (unnormalised) directions fill a box [lo, hi] per axis: a pyramid.  Some ray of it is inside
+// the slab [bmin, bmax] of an axis for the parameters between the smallest and the largest of the four quotients
+// (bmin - o) / lo, (bmin - o) / hi, (bmax - o) / lo, (bmax - o) / hi -- whatever the signs, as long as lo and hi have the
+// same one.  When they straddle zero a ray parallel to the slab belongs to the bundle: nothing bounds the exit, and the
+// bundle is inside from the larger of (bmin - o) / hi and (bmax - o) / lo on (both negative when o is inside the slab).
+// Offsets a = -(o +- e) * i make each quotient one multiply-add; e grows the box by the rounding of o.
+struct BeamSlabsPyr {
+    float i0[3], i1[3], a00[3], a01[3], a10[3], a11[3];
+    uint32_t straddle;
+    RT_DEV void load(const int32_t* state) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            i0[k] = __int_as_float(state[26 + 6 * k]); i1[k] = __int_as_float(state[27 + 6 * k]);
+            a00[k] = __int_as_float(state[28 + 6 * k]); a01[k] = __int_as_float(state[29 + 6 * k]);
+            a10[k] = __int_as_float(state[30 + 6 * k]); a11[k] = __int_as_float(state[31 + 6 * k]);
+        }
+        straddle = (uint32_t)state[44];
+    }
+    RT_DEV bool child(const FastNode& n, int c, float& tnear) const {
+        float tn = 0.0f, tf = __builtin_inff();  // the rays start at the point
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float A = __builtin_fmaf(n.b[c][k][0], i0[k], a00[k]), B = __builtin_fmaf(n.b[c][k][0], i1[k], a01[k]);
+            const float C = __builtin_fmaf(n.b[c][k][1], i0[k], a10[k]), D = __builtin_fmaf(n.b[c][k][1], i1[k], a11[k]);
+            if ((straddle >> k) & 1u) {
+                tn = fmaxf(tn, fmaxf(B, C));
+            } else {
+                tn = fmaxf(tn, fminf(fminf(A, B), fminf(C, D)));
+                tf = fminf(tf, fmaxf(fmaxf(A, B), fmaxf(C, D)));
+            }
+        }
+        tnear = tn;
+        return tn <= tf;
+    }
+};
+
+// Sets up the walk of the pyramid of rays from `org` through pixel (lx, y) of the image plane llc + s horizontal + t vertical
+// (camera_pinhole.go:20-34; a FocusableCamera with no aperture, camera_focusable.go:26-63, is the same from LookFrom).
+RT_DEV void beam_setup_pyr(const DCamera& cam, V3 org, int32_t dx_img, int32_t dy_img, const DMesh& m, int lx, int y, int32_t* state) {
+    const double s0 = (double)lx / (double)dx_img, s1 = (double)(lx + 1) / (double)dx_img;
+    const double t0 = (double)y / (double)dy_img, t1 = (double)(y + 1) / (double)dy_img;
+    const V3 llc = ld3(cam.llc), hz = ld3(cam.horizontal), vt = ld3(cam.vertical);
+    // directions are llc + s horizontal + t vertical - org: linear in (s, t), so the corners of the pixel bound every component
+    const V3 wc = ((llc + hz * (0.5 * (s0 + s1))) + vt * (0.5 * (t0 + t1))) - org;
+    const double lc = sqrt(dot(wc, wc));
+    double lo[3], hi[3], lmin = kMaxFloat;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = kMaxFloat; hi[k] = -kMaxFloat; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const V3 w = ((llc + hz * ((c & 1) ? s1 : s0)) + vt * ((c & 2) ? t1 : t0)) - org;
+        lo[0] = fmin(lo[0], w.x); hi[0] = fmax(hi[0], w.x);
+        lo[1] = fmin(lo[1], w.y); hi[1] = fmax(hi[1], w.y);
+        lo[2] = fmin(lo[2], w.z); hi[2] = fmax(hi[2], w.z);
+        lmin = fmin(lmin, sqrt(dot(w, w)));
+    }
+    const double o3[3] = {org.x - m.center[0], org.y - m.center[1], org.z - m.center[2]};
+    uint32_t straddle = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        // the box of directions in units of the centre ray's length, widened by 2^-21 of its size (float32 rounding of the
+        // bounds and of their reciprocals, and the samples' own arithmetic, all far below that)
+        const double a = lo[k] / lc, b = hi[k] / lc, wide = (fabs(a) + fabs(b)) * 4.76837158203125e-7 + 1e-30;
+        const float flo = -up32(-(a - wide)), fhi = up32(b + wide);
+        const float of = (float)o3[k];
+        const float ef = up32(fabs(o3[k]) * 4.76837158203125e-7 + (double)m.radius * 4.76837158203125e-7);  // 2^-21 (|o| + R)
+        const float i0 = slab_inverse(flo), i1 = slab_inverse(fhi);
+        if (flo <= 0.0f && fhi >= 0.0f) straddle |= 1u << k;
+        state[26 + 6 * k] = __float_as_int(i0);
+        state[27 + 6 * k] = __float_as_int(i1);
+        state[28 + 6 * k] = __float_as_int(-(of + ef) * i0);  // with a box's min plane
+        state[29 + 6 * k] = __float_as_int(-(of + ef) * i1);
+        state[30 + 6 * k] = __float_as_int(-(of - ef) * i0);  // with its max plane
+        state[31 + 6 * k] = __float_as_int(-(of - ef) * i1);
+        state[16 + k] = __float_as_int(of);
+        state[19 + k] = __float_as_int((float)(0.5 * (a + b)));
+        state[22 + k] = __float_as_int(up32(0.5 * (b - a) + wide + fabs(0.5 * (a + b)) * 1.1920929e-7));
+    }
+    state[44] = (int32_t)straddle;
+    // a ray's distance along its unit direction is the slab parameter times the length of its direction in these units: at
+    // least lmin / lc of it
+    state[45] = __float_as_int((float)(lmin / lc * (1.0 - 4.76837158203125e-7)));
+    state[10] = 0;  // the frame's origin is the point itself: no shift along the rays
+    state[11] = 0;
+    state[12] = 0;
+    state[13] = 0;
+    state[14] = 0;
+}
+
 // One instalment of a pixel's walk: up to kBeamCands leaves, (reference, entry distance, face mask) triples in cand.  The
-// walk is over when state[12] == kFastEmpty afterwards.  stack: this lane's own 2 * cap dwords.
-RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int cap, int32_t* cand, bool& overflow
+// walk is over when state[12] == kFastEmpty afterwards.  stack: this lane's own 2 * cap dwords.  `scale` turns the entry
+// parameter into a distance no ray of the bundle undercuts (1 for parallel rays).
+template <typename Slabs>
+RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int cap, int32_t* cand, bool& overflow, float scale
 #ifdef RT_VISIT_STATS
                      , uint32_t& steps
 #endif
 ) {
-    const float ax = __int_as_float(state[0]), ay = __int_as_float(state[1]), az = __int_as_float(state[2]);
-    const float bx = __int_as_float(state[3]), by = __int_as_float(state[4]), bz = __int_as_float(state[5]);
-    const float ix = __int_as_float(state[6]), iy = __int_as_float(state[7]), iz = __int_as_float(state[8]);
-    const float t_lo = __int_as_float(state[9]);
+    Slabs slabs;
+    slabs.load(state);
     int32_t cur = state[12];
     int sp = state[13];
     float cur_tn = __int_as_float(state[14]);
@@ -974,15 +1086,7 @@ RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int 
             float tn[2];
             bool go[2];
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const float x0 = __builtin_fmaf(n.b[k][0][0], ix, ax), x1 = __builtin_fmaf(n.b[k][0][1], ix, bx);
-                const float y0 = __builtin_fmaf(n.b[k][1][0], iy, ay), y1 = __builtin_fmaf(n.b[k][1][1], iy, by);
-                const float z0 = __builtin_fmaf(n.b[k][2][0], iz, az), z1 = __builtin_fmaf(n.b[k][2][1], iz, bz);
-                const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_lo));
-                const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                tn[k] = tnear;
-                go[k] = (tnear <= tfar) && n.child[k] != kFastEmpty;
-            }
+            for (int k = 0; k < 2; k++) go[k] = slabs.child(n, k, tn[k]) && n.child[k] != kFastEmpty;
             if (go[0] && go[1]) {
                 const bool swap = tn[1] < tn[0];
                 if (sp < cap) {
@@ -1003,8 +1107,8 @@ RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int 
         } else {
             if (count == kBeamCands) break;  // the list is full: the next instalment resumes at this leaf
             cand[3 * count] = cur;
-            cand[3 * count + 1] = __float_as_int(cur_tn);
-            cand[3 * count + 2] = (int32_t)(kBeamLeafMask >> (kBeamLeafFaces - 1 - (int)((uint32_t)~cur & (uint32_t)(kBeamLeafFaces - 1))));  // every face of the leaf, until beam_cull_item has looked
+            cand[3 * count + 1] = __float_as_int(cur_tn * scale);
+            cand[3 * count + 2] = (int32_t)(kBeamLeafMask >> (kBeamLeafFaces - 1 - (int)((uint32_t)~cur & (uint32_t)(kBeamLeafFaces - 1))));  // every face of the leaf, until beam_cull_item32 has looked
             count++;
             pop();
         }

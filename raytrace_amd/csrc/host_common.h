@@ -83,8 +83,8 @@ struct Replica {
     // frame's camera direction differs from beam_dir)
     BeamTables beam{};
     int64_t beam_faces = 0;
-    double beam_dir[3] = {0, 0, 0};
-    bool beam_dir_valid = false;
+    double beam_key[3] = {0, 0, 0};  // what the tables were last filled for: a direction, or (beam.pyramid) a point
+    bool beam_key_valid = false;
 };
 
 }  // namespace rt

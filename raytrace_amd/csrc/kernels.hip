@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 
 #include "dev_bvh.h"
 #include "dev_shade.h"
@@ -877,7 +878,8 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
 #define RT_BEAM_WAVES 5  // measured on the 4K scan (items of 4 pixels, 12 compact faces): 4 waves 85.5 ms, 5 waves 78.5 ms, 6 waves (8 compact faces) 90.3 ms
 #endif
 
-// The tables of dev_beam.h for direction (dx, dy, dz): one thread per face, leaf order.
+// The tables of dev_beam.h for direction (dx, dy, dz), or (PYR) for rays from the point (dx, dy, dz): one thread per face, leaf order.
+template <bool PYR>
 __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, double dy, double dz, BeamFace32* __restrict__ f32,
                                                          BeamFace64* __restrict__ f64, double* __restrict__ uv) {
     const DMesh& m = sc.meshes[sc.nodes[0].index];
@@ -885,6 +887,39 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
     if (i >= m.n_faces) return;
     const double* pos = sc.prim_pos + (m.prim_off + i) * 9;
     const V3 p0 = ld3(pos), p1 = ld3(pos + 3), p2 = ld3(pos + 6), d = mk(dx, dy, dz);
+    const double* uv_src = sc.face_uv + (m.face_off + sc.prim_face[m.prim_off + i]) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) uv[i * 6 + k] = uv_src[k];
+    if (PYR) {
+        // shape_mesh.go:99-120 for a ray from the point d: what does not depend on the ray's direction
+        const V3 edge1 = p1 - p0;
+        const V3 edge2 = p2 - p0;
+        const V3 s = d - p0;
+        const V3 q = cross(s, edge1);
+        BeamFace64 o;
+        st3(o.p0, s); st3(o.e1, edge1); st3(o.e2, edge2); st3(o.h, q);
+        o.f = dot(edge2, q);
+        o.pad = 0;
+        f64[i] = o;
+        const Tri32 t = sc.prim_tri32[m.prim_off + i];
+        BeamFace32 r;
+        {
+#pragma clang fp contract(fast)
+            const float ox = (float)(dx - m.center[0]), oy = (float)(dy - m.center[1]), oz = (float)(dz - m.center[2]);
+            const float sx = ox - t.p0[0], sy = oy - t.p0[1], sz = oz - t.p0[2];
+            // U = s . (d x e2) = d . (e2 x s), V = d . (s x e1), a = e1 . (d x e2) = d . (e2 x e1)
+            r.p0[0] = t.e2[1] * sz - t.e2[2] * sy; r.p0[1] = t.e2[2] * sx - t.e2[0] * sz; r.p0[2] = t.e2[0] * sy - t.e2[1] * sx;
+            r.h[0] = sy * t.e1[2] - sz * t.e1[1]; r.h[1] = sz * t.e1[0] - sx * t.e1[2]; r.h[2] = sx * t.e1[1] - sy * t.e1[0];
+            r.g[0] = t.e2[1] * t.e1[2] - t.e2[2] * t.e1[1]; r.g[1] = t.e2[2] * t.e1[0] - t.e2[0] * t.e1[2]; r.g[2] = t.e2[0] * t.e1[1] - t.e2[1] * t.e1[0];
+            // margins of tri32_rejects for directions of length up to 1.01, with the largest |component| of s in the place of the
+            // mesh radius (the rays' origin need not lie inside the mesh's bounds)
+            const float reach = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + m.radius;
+            const float err_d = kErr * 1.01f, err_r = err_d * reach;
+            r.neg_eu = err_r * t.len2; r.neg_ev = err_r * t.len1; r.lim = err_d * t.len1 * t.len2;
+        }
+        f32[i] = r;
+        return;
+    }
     // shape_mesh.go:99-110, as mt_core computes it for every ray
     const V3 edge1 = p1 - p0;
     const V3 edge2 = p2 - p0;
@@ -922,15 +957,13 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
         }
     }
     f32[i] = q;
-    const double* src = sc.face_uv + (m.face_off + sc.prim_face[m.prim_off + i]) * 6;
-#pragma unroll
-    for (int k = 0; k < 6; k++) uv[i * 6 + k] = src[k];
 }
 
 // One work item: pass.block_px (at most kBeamPixels) consecutive pixels of tile v, all samples of the pass.  Dynamic LDS:
 // the walking lanes' stacks (lane j: 2 * cap dwords at j * 2 * cap), then at pass.beam_offset the lists (kBeamPixels x
 // kBeamCands triples), the walks' states, kBeamCullDwords for beam_cull_item32 and the pixels' compact face arrays.
-template <bool IMG>
+// PYR: the rays come from one point (pinhole camera; focusable camera without aperture) instead of sharing a direction.
+template <bool IMG, bool PYR>
 RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const BeamTables& bt, double* __restrict__ film, long long v,
                       uint32_t sub, int p, int cap, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, VisitCounts& vc) {
     const int rounds = (pass.sample_count + 63) >> 6;
@@ -945,6 +978,16 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     int32_t* const beam_compact = beam_state + kBeamPixels * kBeamStateDwords + kBeamCullDwords;
     const DMesh& m = sc.meshes[sc.nodes[0].index];
     const FastNode* const tree = sc.fast_nodes + m.beam_off;
+    typedef typename std::conditional<PYR, BeamSlabsPyr, BeamSlabsOrtho>::type Slabs;
+    const V3 org = cam.kind == RT_CAM_PINHOLE ? ld3(cam.origin) : ld3(cam.from);  // PYR: where every ray starts
+    // sets the walk of pixel (lx, y) up in st; false: its bundle misses the mesh
+    auto setup = [&](int lx, int y, int32_t* st) -> bool {
+        if (PYR) {
+            beam_setup_pyr(cam, org, pass.dx, pass.dy, m, lx, y, st);
+            return true;
+        }
+        return beam_setup(cam, pass.dx, pass.dy, m, lx, y, st);
+    };
     // lane j walks the bundle of pixel j of the item: the first instalment of its list, and whether there is more
     if (p < pass.block_px) {
         int32_t* const st = beam_state + p * kBeamStateDwords;
@@ -955,11 +998,11 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         if (lx < pass.dx && ly < pass.local_rows && row < pass.dy) {
 #ifdef RT_VISIT_STATS
             uint32_t steps = 0;
-            if (beam_setup(cam, pass.dx, pass.dy, m, lx, pass.dy - 1 - row, st)) {
-                found = beam_fill(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow, steps);
+            if (setup(lx, pass.dy - 1 - row, st)) {
+                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f, steps);
 #else
-            if (beam_setup(cam, pass.dx, pass.dy, m, lx, pass.dy - 1 - row, st)) {
-                found = beam_fill(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow);
+            if (setup(lx, pass.dy - 1 - row, st)) {
+                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f);
 #endif
                 if (st[12] != kFastEmpty) found |= 0x100;  // the list goes on: this pixel's rounds walk it in instalments
             }
@@ -968,7 +1011,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    beam_cull_item32(bt.f32, beam_state, beam_cand, beam_state + kBeamPixels * kBeamStateDwords, beam_compact, pass.block_px, p);
+    beam_cull_item32<PYR>(bt.f32, beam_state, beam_cand, beam_state + kBeamPixels * kBeamStateDwords, beam_compact, pass.block_px, p);
     if (p < pass.block_px) {
         const int32_t found = beam_state[p * kBeamStateDwords + 15];
         if (!(found & 0x100)) beam_suffix_min(beam_cand + p * kBeamCands * 3, found & 0xff);
@@ -987,8 +1030,8 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         img_px = im.px; img_w = im.w; img_h = im.h; img_format = im.format;
         img_interp = tx.interp; img_wrap = tx.wrap;
     }
-    const V3 d = ld3(cam.dir);  // every ray of an orthographic camera has the camera's direction (camera_orthographic.go:44)
-    const bool d_sound = !bad3(d);
+    const V3 d_all = ld3(cam.dir);  // every ray of an orthographic camera has the camera's direction (camera_orthographic.go:44)
+    const bool d_sound = PYR || !bad3(d_all);
     for (int pb = 0; pb < pass.block_px; pb++) {
         // all 64 lanes are on this pixel: everything about it is wave-uniform
         const int pix = (int)sub * pass.block_px + pb;
@@ -1015,7 +1058,8 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
             continue;
         }
         // origin of the bundle's float32 frame: a ray's origin in it is o + (d T - centre)
-        const V3 shift = d * beam_T - ld3(m.center);
+        const V3 shift = d_all * beam_T - ld3(m.center);
+        const float scale = PYR ? __int_as_float(__builtin_amdgcn_readfirstlane(px_state[45])) : 1.0f;
         const double xd = (double)lx, yd = (double)y;
         const uint32_t ctr0 = (uint32_t)(y * pass.dx + lx);
         V3 acc = mk(0, 0, 0);
@@ -1033,32 +1077,41 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
             philox4x32_10(blk, k0, k1);
             const double fs = div_by(xd + draw53(blk[0], blk[1]), (double)pass.dx, inv_dx);  // render.go:202-210
             const double ft = div_by(yd + draw53(blk[2], blk[3]), (double)pass.dy, inv_dy);
-            // camera_orthographic.go:24-46
-            const V3 o = (ld3(cam.from) + ld3(cam.u) * (cam.fov_w * (fs - 0.5))) + ld3(cam.v) * (cam.fov_h * (ft - 0.5));
+            V3 o, d;
+            float fx, fy, fz;
+            if (PYR) {  // camera_pinhole.go:20-34 (camera_focusable.go:26-63 with a lens of radius 0: the same from LookFrom)
+                const V3 ip = (ld3(cam.llc) + ld3(cam.horizontal) * fs) + ld3(cam.vertical) * ft;
+                o = org;
+                d = unit(ip - o);
+                fx = (float)d.x; fy = (float)d.y; fz = (float)d.z;
+            } else {  // camera_orthographic.go:24-46
+                o = (ld3(cam.from) + ld3(cam.u) * (cam.fov_w * (fs - 0.5))) + ld3(cam.v) * (cam.fov_h * (ft - 0.5));
+                d = d_all;
+                fx = (float)(o.x + shift.x); fy = (float)(o.y + shift.y); fz = (float)(o.z + shift.z);
+            }
             bool sound = traced && d_sound;
-            if (!bt.safe_camera) sound = sound && !bad3(o);  // render.go:147-150
+            if (!bt.safe_camera) sound = sound && !(PYR ? bad3(d) : bad3(o));  // render.go:147-150
             BeamHit bh{false, __builtin_inff(), 0, kMaxFloat, 0, 0};
-            const float fx = (float)(o.x + shift.x), fy = (float)(o.y + shift.y), fz = (float)(o.z + shift.z);
             bool walking = beam_long;  // wave-uniform
-            if (walking && p == pb) beam_setup(cam, pass.dx, pass.dy, m, lx, y, px_state);  // this round's walk starts over
+            if (walking && p == pb) setup(lx, y, px_state);  // this round's walk starts over
 #ifdef RT_VISIT_STATS
             const long long faces_t0 = clock64();
 #endif
-            if (use_compact) beam_test_compact(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, bh);
+            if (use_compact) beam_test_compact<PYR>(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, bh);
             else do {
                 int n = beam_first;
                 if (walking) {
 #ifdef RT_VISIT_STATS
                     uint32_t again = 0;
-                    if (p == pb) px_state[15] = beam_fill(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, vc.overflow, again);
+                    if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, vc.overflow, scale, again);
 #else
-                    if (p == pb) px_state[15] = beam_fill(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, vc.overflow);
+                    if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, vc.overflow, scale);
 #endif
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     n = __builtin_amdgcn_readfirstlane(px_state[15]);
                 }
-                if (n > 0) beam_test_prepared(bt, o, d, fx, fy, fz, beam_T, px_cand, n, !beam_long, kEps, sound, bh);
+                if (n > 0) beam_test_prepared<PYR>(bt, o, d, fx, fy, fz, beam_T, px_cand, n, !beam_long, kEps, sound, bh);
                 if (walking) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -1106,7 +1159,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     }
 }
 
-template <bool IMG>
+template <bool IMG, bool PYR>
 __global__ void __launch_bounds__(kTraceBlock, RT_BEAM_WAVES) k_beam(DScene sc, const DCamera* __restrict__ camp, PassDesc pass, Counters* __restrict__ counters,
                                                                      BeamTables bt, double* __restrict__ film) {
     const DCamera& cam = *camp;
@@ -1151,7 +1204,7 @@ __global__ void __launch_bounds__(kTraceBlock, RT_BEAM_WAVES) k_beam(DScene sc, 
         if (v < 0) break;
         sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
         const long long t_start = pass.cost ? clock64() : 0;
-        beam_item<IMG>(sc, cam, pass, bt, film, v, sub, p, sc.stack_pairs, n_total, n_left, n_culled, vc);
+        beam_item<IMG, PYR>(sc, cam, pass, bt, film, v, sub, p, sc.stack_pairs, n_total, n_left, n_culled, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
     }
     if (p == 0) {  // the tallies are per wave already
@@ -1857,9 +1910,11 @@ static unsigned persistent_grid(K kernel, size_t lds, int block = kTraceBlock) {
 
 int beam_pixels_max() { return kBeamPixels; }
 
-void launch_beam_prepare(const DScene& sc, int64_t n_faces, const double dir[3], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s) {
+void launch_beam_prepare(const DScene& sc, int64_t n_faces, bool pyr, const double key[3], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s) {
     if (n_faces <= 0) return;
-    hipLaunchKernelGGL(k_beam_prepare, dim3(blocks_for((size_t)n_faces)), dim3(kBlock), 0, s, sc, dir[0], dir[1], dir[2], f32, f64, uv);
+    const dim3 grid(blocks_for((size_t)n_faces)), block(kBlock);
+    if (pyr) hipLaunchKernelGGL(k_beam_prepare<true>, grid, block, 0, s, sc, key[0], key[1], key[2], f32, f64, uv);
+    else hipLaunchKernelGGL(k_beam_prepare<false>, grid, block, 0, s, sc, key[0], key[1], key[2], f32, f64, uv);
 }
 
 size_t beam_table_bytes(int64_t n_faces, size_t* off_f64, size_t* off_uv) {
@@ -1888,8 +1943,8 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
         const unsigned waves = std::min(resident, (tiles + 7u) & ~7u);
         hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), lds, s, sc, cam, pd, counters, bt, film);
     };
-    if (bt.image) go(k_beam<true>);
-    else go(k_beam<false>);
+    if (bt.pyramid) { if (bt.image) go(k_beam<true, true>); else go(k_beam<false, true>); }
+    else { if (bt.image) go(k_beam<true, false>); else go(k_beam<false, false>); }
     return true;
 }
 

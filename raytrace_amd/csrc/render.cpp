@@ -605,23 +605,46 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     int64_t item_rays = 256;   // measured 64 / 128 / 256 / 512, Grays/s: scan-lit 5.54 / 5.53 / 5.44 / 5.20, material 7.31 / 7.30 / 7.28 / 7.18, teapot 5.43 / 5.50 / 5.54 / 5.56, charuco orbit 610 / 670 / 681 / 662 frames/s
     if (const char* e = getenv("RT_LOG2_LANES")) lanes_override = std::max(0, atoi(e));
     // Pixel beams (one tree walk per pixel instead of one per 64 samples, see dev_bvh.h): parallel rays through one mesh.
-    const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && cam.kind == RT_CAM_ORTHOGRAPHIC &&
-                      rep.beam_faces > 0 && o->rays_per_pixel > 1 && !getenv("RT_NO_BEAM");
+    // Orthographic: the rays share a direction.  Pinhole, or focusable with a lens of radius 0 (camera_focusable.go:26-63: the
+    // lens offset is then zero, whatever is drawn): they share their origin, and the image plane must not pass through it.
+    bool beam_pyr = false;
+    double beam_key[3] = {cam.dir[0], cam.dir[1], cam.dir[2]};
+    bool beam_cam = cam.kind == RT_CAM_ORTHOGRAPHIC;
+    if (cam.kind == RT_CAM_PINHOLE || (cam.kind == RT_CAM_FOCUSABLE && cam.lens_radius == 0)) {
+        const double* org = cam.kind == RT_CAM_PINHOLE ? cam.origin : cam.from;
+        const double n[3] = {cam.horizontal[1] * cam.vertical[2] - cam.horizontal[2] * cam.vertical[1], cam.horizontal[2] * cam.vertical[0] - cam.horizontal[0] * cam.vertical[2],
+                             cam.horizontal[0] * cam.vertical[1] - cam.horizontal[1] * cam.vertical[0]};
+        const double nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        const double away = ((cam.llc[0] - org[0]) * n[0] + (cam.llc[1] - org[1]) * n[1] + (cam.llc[2] - org[2]) * n[2]) / nn;
+        const double extent = std::sqrt(cam.horizontal[0] * cam.horizontal[0] + cam.horizontal[1] * cam.horizontal[1] + cam.horizontal[2] * cam.horizontal[2]) +
+                              std::sqrt(cam.vertical[0] * cam.vertical[0] + cam.vertical[1] * cam.vertical[1] + cam.vertical[2] * cam.vertical[2]);
+        beam_cam = beam_pyr = std::isfinite(away) && std::isfinite(extent) && std::fabs(away) > 1e-9 * extent;
+        for (int k = 0; k < 3; k++) beam_key[k] = org[k];
+    }
+    const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && beam_cam && rep.beam_faces > 0 &&
+                      o->rays_per_pixel > 1 && !getenv("RT_NO_BEAM");
     if (beam) {
-        // the tables belong to a direction: every ray of the frame has the camera's (camera_orthographic.go:44)
-        if (!rep.beam_dir_valid || std::memcmp(rep.beam_dir, cam.dir, sizeof(rep.beam_dir)) != 0) {
-            launch_beam_prepare(rep.dev, rep.beam_faces, cam.dir, const_cast<BeamFace32*>(rep.beam.f32), const_cast<BeamFace64*>(rep.beam.f64),
+        // the tables belong to a direction (every ray of an orthographic frame has the camera's, camera_orthographic.go:44) or to a point
+        if (!rep.beam_key_valid || (rep.beam.pyramid != 0) != beam_pyr || std::memcmp(rep.beam_key, beam_key, sizeof(rep.beam_key)) != 0) {
+            launch_beam_prepare(rep.dev, rep.beam_faces, beam_pyr, beam_key, const_cast<BeamFace32*>(rep.beam.f32), const_cast<BeamFace64*>(rep.beam.f64),
                                 const_cast<double*>(rep.beam.uv), stream);
             HIP_TRY(hipGetLastError());
-            std::memcpy(rep.beam_dir, cam.dir, sizeof(rep.beam_dir));
-            rep.beam_dir_valid = true;
+            std::memcpy(rep.beam_key, beam_key, sizeof(rep.beam_key));
+            rep.beam_key_valid = true;
+            rep.beam.pyramid = beam_pyr ? 1 : 0;
         }
-        // Origins are from + u a + v b with |a| <= |FOVWidth| / 2, |b| <= |FOVHeight| / 2: finite constants far from the
-        // float64 range cannot produce a NaN or an infinity, so the guard of render.go:147-150 never fires and is left out
+        // Finite constants far from the float64 range cannot produce a NaN or an infinity in a ray (orthographic: origins
+        // from + u a + v b with |a| <= |FOVWidth| / 2, |b| <= |FOVHeight| / 2; from a point: unit(llc + s h + t v - o) with a
+        // non-zero argument), so the guard of render.go:147-150 never fires and is left out
         bool safe = true;
-        for (int k = 0; k < 3; k++)
-            for (double c : {cam.from[k], cam.u[k], cam.v[k], cam.dir[k]}) safe = safe && std::isfinite(c) && std::fabs(c) < 1e150;
-        safe = safe && std::isfinite(cam.fov_w) && std::isfinite(cam.fov_h) && std::fabs(cam.fov_w) < 1e150 && std::fabs(cam.fov_h) < 1e150;
+        if (beam_pyr) {
+            for (int k = 0; k < 3; k++)
+                for (double c : {cam.llc[k], cam.horizontal[k], cam.vertical[k], beam_key[k]}) safe = safe && std::isfinite(c) && std::fabs(c) < 1e150;
+        } else {
+            for (int k = 0; k < 3; k++)
+                for (double c : {cam.from[k], cam.u[k], cam.v[k], cam.dir[k]}) safe = safe && std::isfinite(c) && std::fabs(c) < 1e150;
+            safe = safe && std::isfinite(cam.fov_w) && std::isfinite(cam.fov_h) && std::fabs(cam.fov_w) < 1e150 && std::fabs(cam.fov_h) < 1e150;
+        }
         rep.beam.safe_camera = safe ? 1 : 0;
     }
     const bool item_rays_fixed = getenv("RT_ITEM_RAYS") != nullptr;

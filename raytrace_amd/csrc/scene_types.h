@@ -158,6 +158,8 @@ struct BeamTables {
     const double* uv;
     int32_t safe_camera;  // 1: every origin the camera can produce is finite (the host has looked at its constants): the NaN / Inf guard of render.go:147-150 cannot fire
     int32_t image;        // 1: the material is an Emitter whose texture is a TextureImage (the kernel samples it in line)
+    int32_t pyramid;      // 0: the tables are for a direction (orthographic camera); 1: for a point every ray starts from (pinhole camera, focusable camera without aperture)
+    int32_t pad;
 };
 
 struct DCamera {

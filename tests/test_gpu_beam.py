@@ -160,3 +160,63 @@ def test_beam_kernel_at_the_bench_size_equals_the_packet_walk_and_the_oracle(ob,
     err = np.abs(beam[mask] - ref[mask]) / np.maximum(np.abs(ref[mask]), 1.0)
     assert err.max() < 1e-12, err.max()
     assert (ref[mask] > 0).any(axis=1).mean() > 0.2  # the sample is not all background
+
+
+def _pinhole(origin, look_at, vup, fov_deg, aspect):
+    """A PinholeCamera (camera_pinhole.go:12-34) looking from origin at look_at: image plane at unit distance."""
+    o, a, up = (np.asarray(v, dtype=float) for v in (origin, look_at, vup))
+    w = (o - a) / np.linalg.norm(o - a)
+    u = np.cross(up, w)
+    u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    hh = np.tan(np.radians(fov_deg) / 2)
+    hw = hh * aspect
+    llc = o - hw * u - hh * v - w
+    return phys.PinholeCamera(tuple(llc), tuple(o), tuple(2 * hw * u), tuple(2 * hh * v))
+
+
+PYRAMID_VIEWS = {
+    # (camera, note)
+    "pinhole_outside": lambda asp: _pinhole((260.0, 40.0, 90.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 52.0, asp),
+    "pinhole_far_narrow": lambda asp: _pinhole((9000.0, -2500.0, 3100.0), (5.0, 0.0, -3.0), (0.0, 0.0, 1.0), 1.6, asp),   # a long lens: the point is far from the mesh frame
+    "pinhole_inside": lambda asp: _pinhole((3.0, -2.0, 5.0), (60.0, 40.0, 10.0), (0.0, 0.0, 1.0), 95.0, asp),            # inside the mesh: every ray hits from within
+    "pinhole_axis_aligned": lambda asp: _pinhole((0.0, 0.0, 400.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, asp),          # pixels whose directions straddle zero in x and y
+    "focusable_no_aperture": lambda asp: phys.FocusableCamera(LookFrom=(210.0, -120.0, 60.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0),
+                                                               FOVHeight=1.1, FOVWidth=1.1 * asp, Aperture=0.0, WorkingDistance=250.0),
+}
+
+
+@pytest.mark.parametrize("view", sorted(PYRAMID_VIEWS))
+def test_beams_from_one_point_equal_the_packet_walk_and_the_oracle(ob, monkeypatch, view):
+    """Pinhole cameras, and focusable cameras without aperture, start every ray at one point: their pixels' bundles are
+    pyramids, walked once per pixel like the parallel bundles of an orthographic camera.  Same bar: the packet walk's image
+    and statistics exactly, the oracle's to one level."""
+    dx, dy, spp = 144, 96, 64
+    base = scenes.scan(level=5, dx=dx, dy=dy, spp=spp, tex_size=64)
+    cam = PYRAMID_VIEWS[view](dx / dy)
+    sc = phys.Scene(Camera=[cam], Node=base.Node, RenderOptions=phys.RenderOptions(2, spp, 6, dx, dy))
+    beam, packet = _both(sc, monkeypatch)
+    assert np.array_equal(beam.Image, packet.Image), view
+    assert _stats(beam.Stats) == _stats(packet.Stats), view
+    with ob.OracleScene(sc) as orc:
+        img, st, _, _ = orc.render(cam, sc.RenderOptions)
+    assert beam.Stats.TotalRays == st.total_rays and beam.Stats.RaysLeftScene == st.rays_left_scene, view
+    diff = np.abs(beam.Image.astype(int) - img.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, view
+    assert (img[..., :3].max(axis=2) > 0).mean() > 0.15, view  # the mesh is in the frame
+
+
+def test_pyramid_beams_on_a_sheet_seen_at_a_grazing_angle(ob, monkeypatch):
+    faces = grid_mesh()
+    cam = _pinhole((2.6, 0.3, 0.08), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 35.0, 120 / 56)  # lists far beyond one instalment
+    tex = phys.TextureCheckerboard(phys.TextureUniform((0.9, 0.3, 0.2)), phys.TextureUniform((0.1, 0.5, 0.9)), 40.0)
+    sc = phys.Scene(Camera=[cam], Node=[phys.Node("sheet", phys.NewMesh(faces), phys.Emitter(tex))], RenderOptions=phys.RenderOptions(3, 64, 4, 120, 56))
+    beam, packet = _both(sc, monkeypatch)
+    assert np.array_equal(beam.Image, packet.Image)
+    assert _stats(beam.Stats) == _stats(packet.Stats)
+    assert 0 < beam.Stats.RaysLeftScene < beam.Stats.TotalRays
+    with ob.OracleScene(sc) as orc:
+        img, st, _, _ = orc.render(cam, sc.RenderOptions)
+    assert beam.Stats.RaysLeftScene == st.rays_left_scene
+    diff = np.abs(beam.Image.astype(int) - img.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
