@@ -38,6 +38,9 @@ func init() {
 	if len(ids) > 0 {
 		p = &ids[0]
 	}
+	// rt_last_error() is thread local: the call and the read of its message must run on one OS thread
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	if rc := C.rt_init(p, C.int(len(ids))); rc != C.RT_OK {
 		panic("rt_init: " + C.GoString(C.rt_last_error()))
 	}
@@ -91,8 +94,15 @@ func renderScene(ctx context.Context, scene *Scene, camera Camera) (RenderArtifa
 		return RenderArtifact{}, err
 	}
 	var h *C.rt_scene
-	if rc := C.rt_scene_create(&flat.desc, &h); rc != C.RT_OK {
-		return RenderArtifact{}, fmt.Errorf("rt_scene_create: %s", C.GoString(C.rt_last_error()))
+	runtime.LockOSThread() // rt_last_error() is thread local
+	rc := C.rt_scene_create(&flat.desc, &h)
+	msg := ""
+	if rc != C.RT_OK {
+		msg = C.GoString(C.rt_last_error())
+	}
+	runtime.UnlockOSThread()
+	if rc != C.RT_OK {
+		return RenderArtifact{}, fmt.Errorf("rt_scene_create: %s", msg)
 	}
 	defer C.rt_scene_destroy(h) // a frame loop keeps h and changes only the camera
 	o := scene.RenderOptions
