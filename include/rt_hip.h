@@ -396,7 +396,15 @@ int rt_film_resolve(const double* film_dev, int32_t dx, int32_t dy, int32_t rays
                     uint8_t* rgba_out, size_t stride, void* stream);
 
 /* Request cancellation of the render running on `scene` (from another thread).
- * rt_render then returns RT_ERR_CANCELLED; mirrors ctx.Done() (render.go:229-233, 340-343). */
+ * The running rt_render / rt_render_film / rt_render_film_noalloc /
+ * rt_render_frames call then returns RT_ERR_CANCELLED; mirrors ctx.Done()
+ * (render.go:229-233, 340-343).  The request is looked at before every kernel
+ * launch of a frame, once more when a frame's last launch has ended (a frame
+ * that is a single launch still reports it) and between the frames of
+ * rt_render_frames.  It belongs to the call that is running: every render
+ * entry point clears it when it begins, so a request that arrives when no call
+ * runs is dropped, as a cancelled context no longer matters once Render has
+ * returned. */
 void rt_cancel(rt_scene* scene);
 
 /* Closest hit of n rays against the scene, the loop of tracePath over

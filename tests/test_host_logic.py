@@ -141,3 +141,44 @@ def test_three_instruction_division_is_the_ieee_quotient():
             assert div_by(n, d) == n / d, (n, d)
         for x in range(min(d, 500)):
             assert div_by(x + 0.5, d) == (x + 0.5) / d
+
+
+def test_bench_gpus_n_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
+    """`bench.py --gpus N` as one process (no WORLD_SIZE): the ranks are started through torch.distributed.run on 127.0.0.1, with the
+    caller's arguments, and the parent takes the child's exit code -- checked here on the command it builds."""
+    import subprocess
+    import sys
+    import types
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    a = types.SimpleNamespace(gpus=4)
+    assert bench.self_launch(a) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_stored_counters_are_tied_to_the_device_sources():
+    import json
+    import os
+    import bench
+    h = bench.source_hash()
+    assert len(h) == 16 and int(h, 16) >= 0 and h == bench.source_hash()
+    stored = json.load(open(os.path.join(bench.ROOT, "profiles", "counters.json")))
+    assert "csrc_sha16" in stored and stored["kernel"].startswith("k_beam")
+    # the floor the roofline prices: every stage named once, positive, and below what the kernel was measured to execute
+    stages = [s for s, _, _, _ in bench.VALU_FLOOR]
+    assert len(stages) == len(set(stages)) and all(n > 0 for _, _, n, _ in bench.VALU_FLOOR)
+    assert {who for _, who, _, _ in bench.VALU_FLOOR} == {"every ray", "listed", "hit"}
+    worst = sum(n for _, _, n, _ in bench.VALU_FLOOR)  # a round in which every ray hits
+    assert worst < stored["valu_insts_per_wave_of_64_rays"] * 1.5
