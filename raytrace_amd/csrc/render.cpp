@@ -694,10 +694,13 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 int64_t want_rays = item_rays;
                 if (beam && !item_rays_fixed) {
                     // Pixel beams: a lane walks the tree for each pixel of an item, so more pixels keep more lanes busy in that
-                    // phase (eight at most); against that an item should not run much longer than 4096 rays and a resident wave
-                    // should get some 120 items, or the last items of the launch leave the chip waiting.  Measured on the 4K scan
-                    // and on a half, a quarter and an eighth of it (1024 samples: 4 / 4 / 4 / 2 pixels; 256 samples: 8 and 4).
-                    int64_t px = std::min<int64_t>(std::min<int64_t>(8, std::max<int64_t>(1, tiles_total * 64 / 491520)), std::max<int64_t>(1, 4096 / s_count));
+                    // phase (kBeamPixels at most); against that an item should not run much longer than 4096 rays, and the fewer
+                    // items a resident wave gets the longer the chip waits for the last ones.  Measured with k_beam on the 4K scan
+                    // at 1024 samples (ms per frame share, items of 1 / 2 / 4 pixels): whole frame 106.6 / 92.0 / 84.0, a quarter of
+                    // it 26.7 / 22.8 / 24.9, an eighth 13.9 / 12.9 / 16.5.
+                    const int64_t share_px = tiles_total * 64;
+                    int64_t px = share_px >= 3000000 ? 4 : (share_px >= 600000 ? 2 : 1);
+                    px = std::min<int64_t>(px, std::max<int64_t>(1, 4096 / s_count));
                     px = std::max<int64_t>(px, std::min<int64_t>(8, 1024 / std::max(1, s_count)));
                     while (px & (px - 1)) px &= px - 1;  // down to a power of two
                     want_rays = px * s_count;
