@@ -220,3 +220,41 @@ def test_pyramid_beams_on_a_sheet_seen_at_a_grazing_angle(ob, monkeypatch):
     assert beam.Stats.RaysLeftScene == st.rays_left_scene
     diff = np.abs(beam.Image.astype(int) - img.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_meshes_and_cameras_beam_equals_packet_walk(monkeypatch, seed):
+    """Random triangle soups (faces of every size and orientation, overlapping, some nearly edge-on to the rays) under random
+    orthographic, pinhole and aperture-free focusable cameras, placed near, far, and inside the mesh: whatever the bundle's
+    conservative tests let through, the image and the counters must be the packet walk's."""
+    rng = np.random.default_rng(1000 + seed)
+    n_faces = int(rng.choice([60, 400, 3000]))
+    faces = scenes.random_faces(n_faces, seed=200 + seed)  # vertices in [-50, 50]^3: triangles as large as the mesh
+    if seed % 2 == 1:  # small triangles: each shrunk towards its centroid
+        c = faces[:, :, :3].mean(axis=1, keepdims=True)
+        faces[:, :, :3] = c + 0.08 * (faces[:, :, :3] - c)
+    if seed % 3 == 0:  # slivers and a few degenerate faces among them
+        faces[::7, 2, :3] = faces[::7, 1, :3] + 1e-9 * rng.standard_normal((len(faces[::7]), 3))
+    kind = ["ortho", "pinhole", "focusable"][seed % 3]
+    dist = float(rng.choice([20.0, 160.0, 5000.0]))
+    d = rng.standard_normal(3)
+    d /= np.linalg.norm(d)
+    if seed in (4, 7):
+        d = np.array([0.0, 0.0, 1.0]) if seed == 4 else np.array([1.0, 0.0, 0.0])  # axis-aligned: zero direction components
+    frm = tuple(d * dist)
+    up = (0.0, 1.0, 0.0) if abs(d[1]) < 0.9 else (1.0, 0.0, 0.0)
+    dx, dy = 96, 64
+    if kind == "ortho":
+        cam = phys.OrthographicCamera(LookFrom=frm, LookAt=(0.0, 0.0, 0.0), VUp=up, FOVHeight=90.0, FOVWidth=90.0 * dx / dy)
+    elif kind == "pinhole":
+        cam = _pinhole(frm, (0.0, 0.0, 0.0), up, float(np.degrees(2 * np.arctan(60.0 / max(dist, 30.0)))), dx / dy)
+    else:
+        h = 2 * 60.0 / max(dist, 30.0)
+        cam = phys.FocusableCamera(LookFrom=frm, LookAt=(0.0, 0.0, 0.0), VUp=up, FOVHeight=h, FOVWidth=h * dx / dy, Aperture=0.0, WorkingDistance=dist)
+    tex = phys.TextureCheckerboard(phys.TextureUniform((0.9, 0.3, 0.2)), phys.TextureUniform((0.1, 0.5, 0.9)), 9.0)
+    mat = [phys.Emitter(tex), phys.DebugUV(), phys.DebugNormal()][seed % 3 if seed < 6 else 0]
+    sc = phys.Scene(Camera=[cam], Node=[phys.Node("soup", phys.NewMesh(faces), mat)], RenderOptions=phys.RenderOptions(seed, 64, 3, dx, dy))
+    beam, packet = _both(sc, monkeypatch)
+    assert np.array_equal(beam.Image, packet.Image), (seed, kind, dist)
+    assert _stats(beam.Stats) == _stats(packet.Stats), (seed, kind, dist)
+    assert beam.Stats.RaysLeftScene < beam.Stats.TotalRays, (seed, kind, dist)  # something is hit
