@@ -196,13 +196,20 @@ RT_DEV void beam_patch_distances(const int32_t* beam_state, const int32_t* beam_
 // o, d: the ray (PYR: o is not read, the table holds s = o - p0; else d is the same for every lane).
 template <bool PYR>
 RT_DEV void beam_face64(const BeamTables& bt, int32_t face, V3 o, V3 d, double T, double tmin, bool maybe, BeamHit& bh) {
-    const RT_CONST_AS double* p = (const RT_CONST_AS double*)(bt.f64 + face);
     const double e = 1e-8;
     double t = 0, u = 0, v = 0;
     bool ok = false;
+    // The whole prepared face in one batch of scalar loads, all seven in flight before anything waits for one of them: left to
+    // itself the compiler moves each load below the branch that first needs it, which makes up to four dependent round trips
+    // of one (4 % of the 4K scan frame, 7 % of an eighth of it).
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const RT_CONST_AS f64x2* pv = (const RT_CONST_AS f64x2*)(bt.f64 + face);
+    const f64x2 a0 = pv[0], a1 = pv[1], a2 = pv[2], a3 = pv[3], a4 = pv[4], a5 = pv[5], a6 = pv[6];
+    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6));
+    const double pp[13] = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1], a4[0], a4[1], a5[0], a5[1], a6[0]};
     if (PYR) {
         if (maybe) {
-            const V3 s = mk(p[0], p[1], p[2]), edge1 = mk(p[3], p[4], p[5]), edge2 = mk(p[6], p[7], p[8]), q = mk(p[9], p[10], p[11]);
+            const V3 s = mk(pp[0], pp[1], pp[2]), edge1 = mk(pp[3], pp[4], pp[5]), edge2 = mk(pp[6], pp[7], pp[8]), q = mk(pp[9], pp[10], pp[11]);
             const V3 h = cross(d, edge2);
             const double a = dot(edge1, h);
             if (!(a > -e && a < e)) {
@@ -211,18 +218,13 @@ RT_DEV void beam_face64(const BeamTables& bt, int32_t face, V3 o, V3 d, double T
                 if (!(u < -e || u > 1.0 + e)) {
                     v = f * dot(d, q);
                     if (!(v < -e || u + v > 1.0 + e)) {
-                        t = f * p[12];
+                        t = f * pp[12];
                         ok = !(t < tmin || t > bh.t);
                     }
                 }
             }
         }
     } else {
-        // the whole prepared face in one batch of scalar loads: one round trip instead of one per stage of the test
-        typedef double f64x2 __attribute__((ext_vector_type(2)));
-        const RT_CONST_AS f64x2* pv = (const RT_CONST_AS f64x2*)(bt.f64 + face);
-        const f64x2 a0 = pv[0], a1 = pv[1], a2 = pv[2], a3 = pv[3], a4 = pv[4], a5 = pv[5], a6 = pv[6];
-        const double pp[13] = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1], a4[0], a4[1], a5[0], a5[1], a6[0]};
         const double f = pp[12];
         // a face the reference rejects whatever the ray (shape_mesh.go:107-109): f is NaN, all bits of its exponent set
         if (((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(__double_as_longlong(f) >> 32)) & 0x7ff00000u) == 0x7ff00000u) return;
