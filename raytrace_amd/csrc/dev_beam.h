@@ -326,13 +326,15 @@ RT_DEV V3 image_at_uniform(const uint8_t* px, int w, int h, int format, int inte
         const int xa = clampi(x0, 0, w - 1), xb = clampi(x0 + 1, 0, w - 1), ya = clampi(y0, 0, h - 1), yb = clampi(y0 + 1, 0, h - 1);
         uint32_t t[4][3];
         if (format == RT_IMG_RGBA16) {
-            const uint2* q = reinterpret_cast<const uint2*>(px);
-            const uint2 a = q[(size_t)ya * w + xa], b = q[(size_t)ya * w + xb], cc = q[(size_t)yb * w + xa], dd = q[(size_t)yb * w + xb];
-            const uint2 all[4] = {a, b, cc, dd};
+            const RT_GLOBAL_AS unsigned long long* q = (const RT_GLOBAL_AS unsigned long long*)px;  // global, not flat, loads: they do not wait on LDS traffic
+            const unsigned long long all[4] = {q[(size_t)ya * w + xa], q[(size_t)ya * w + xb], q[(size_t)yb * w + xa], q[(size_t)yb * w + xb]};
 #pragma unroll
-            for (int k = 0; k < 4; k++) { t[k][0] = all[k].x & 0xffffu; t[k][1] = all[k].x >> 16; t[k][2] = all[k].y & 0xffffu; }
+            for (int k = 0; k < 4; k++) {
+                const uint32_t lo = (uint32_t)all[k], hi = (uint32_t)(all[k] >> 32);
+                t[k][0] = lo & 0xffffu; t[k][1] = lo >> 16; t[k][2] = hi & 0xffffu;
+            }
         } else {  // color.NRGBA.RGBA(): v = v * 0x101 * a / 0xff
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(px);
+            const RT_GLOBAL_AS uint32_t* q = (const RT_GLOBAL_AS uint32_t*)px;
             const uint32_t all[4] = {q[(size_t)ya * w + xa], q[(size_t)ya * w + xb], q[(size_t)yb * w + xa], q[(size_t)yb * w + xb]};
 #pragma unroll
             for (int k = 0; k < 4; k++) {

@@ -8,6 +8,8 @@
 #include <cstdint>
 
 #define RT_DEV __device__ __forceinline__
+// a pointer read from memory (not a kernel argument) is generic to the compiler; one that is known to point into device memory is cast to this
+#define RT_GLOBAL_AS __attribute__((address_space(1)))
 #define RT_HD __host__ __device__ __forceinline__
 
 namespace rt {

@@ -9,12 +9,12 @@ namespace rt {
 // image.At(x, y).RGBA(): alpha-premultiplied 16-bit channels.
 RT_DEV void texel16(const DImage& im, int x, int y, uint32_t c[3]) {
     if (im.format == RT_IMG_RGBA16) {
-        const uint16_t* p = reinterpret_cast<const uint16_t*>(im.px) + ((size_t)y * im.w + x) * 4;
+        const RT_GLOBAL_AS uint16_t* p = (const RT_GLOBAL_AS uint16_t*)im.px + ((size_t)y * im.w + x) * 4;  // global, not flat, loads
         c[0] = p[0]; c[1] = p[1]; c[2] = p[2];
     } else {  // color.NRGBA.RGBA(): v = v * 0x101 * a / 0xff
-        const uchar4 q = reinterpret_cast<const uchar4*>(im.px)[(size_t)y * im.w + x];
-        const uint32_t a = q.w;
-        uint32_t r = q.x, g = q.y, b = q.z;
+        const uint32_t q = ((const RT_GLOBAL_AS uint32_t*)im.px)[(size_t)y * im.w + x];
+        const uint32_t a = q >> 24;
+        uint32_t r = q & 0xffu, g = (q >> 8) & 0xffu, b = (q >> 16) & 0xffu;
         r |= r << 8; g |= g << 8; b |= b << 8;
         if (a != 0xff) {  // opaque texels (nearly all of them) keep v * 0x101: v * 0x101 * 255 / 255
             r *= a; r /= 0xff;
