@@ -696,10 +696,10 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                     // Pixel beams: a lane walks the tree for each pixel of an item, so more pixels keep more lanes busy in that
                     // phase (kBeamPixels at most); against that an item should not run much longer than 4096 rays, and the fewer
                     // items a resident wave gets the longer the chip waits for the last ones.  Measured with k_beam on the 4K scan
-                    // at 1024 samples (ms per frame share, items of 1 / 2 / 4 pixels): whole frame 106.6 / 92.0 / 84.0, a quarter of
-                    // it 26.7 / 22.8 / 24.9, an eighth 13.9 / 12.9 / 16.5.
+                    // at 1024 samples (ms per frame share, items of 1 / 2 / 4 pixels): whole frame 100.6 / 89.7 / 82.0, a quarter of
+                    // it 25.9 / 22.5 / 21.7, an eighth 13.6 / 11.6 / 14.6.
                     const int64_t share_px = tiles_total * 64;
-                    int64_t px = share_px >= 3000000 ? 4 : (share_px >= 600000 ? 2 : 1);
+                    int64_t px = share_px >= 1500000 ? 4 : (share_px >= 600000 ? 2 : 1);
                     px = std::min<int64_t>(px, std::max<int64_t>(1, 4096 / s_count));
                     px = std::max<int64_t>(px, std::min<int64_t>(8, 1024 / std::max(1, s_count)));
                     while (px & (px - 1)) px &= px - 1;  // down to a power of two
