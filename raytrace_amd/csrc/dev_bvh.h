@@ -20,6 +20,9 @@ struct VisitCounts {
 };
 
 // Diagnostics (builds with -DRT_VISIT_STATS only): events per wave, summed over the launch.
+#ifdef RT_WAVE_TIMES  // diagnostics build: when the persistent waves of k_beam begin and end
+__device__ unsigned long long g_wave_times[3 * 8192];  // per wave: start, end (constant-rate clock), items traced
+#endif
 #ifdef RT_VISIT_STATS
 __device__ unsigned long long g_packet_stats[16];  // packet walk: walks, inner nodes, leaves, float32 face tests, float64 face tests, pops, pushes, -, cycles in walks, cycles in rounds, rounds, cycles in leaves
 __device__ unsigned long long g_trace_stats[64][64];   // k_trace / k_direct, striped by workgroup; see render.cpp's print-out
@@ -890,7 +893,8 @@ constexpr uint32_t kBeamLeafMask = (1u << kBeamLeafFaces) - 1u;  // one bit per 
 // p * i + a, of a max plane p * i + b), 6-8 i = 1 / direction, 9 t_lo (where the rays start, in the bundle's frame),
 // 10-11 T (float64: the frame starts at o + d * T), 12 cur, 13 sp, 14 entry distance of cur, 15 the caller's (length
 // of the list), 16-18 origin of the centre ray in that frame, 19-21 half-extent of the footprint (margins included),
-// 22-24 direction (float32).  25: survivors of the pixel's list (beam_cull_item32).
+// 22-24 direction (float32).  25: survivors of the pixel's list (beam_cull_item32), then those of them that the compact array
+// holds; 46: the leaf at which the list goes on after them (beam_compact_prefix).
 // A pyramid of rays from one point (beam_setup_pyr) uses instead: 16-18 the point in the mesh frame, 19-21 the centre of the
 // box of its directions, 22-24 that box's half-widths, 26-43 per axis (1 / d_lo, 1 / d_hi and the four offsets of
 // beam_child_pyr), 44 bit k set = the directions' k-th components straddle zero, 45 factor from slab parameter to distance.
@@ -1129,6 +1133,20 @@ RT_DEV void beam_suffix_min(int32_t* cand, int n) {
         if (cand[3 * c + 2] != 0) m = fminf(m, __int_as_float(cand[3 * c + 1]));
         cand[3 * c + 1] = __float_as_int(m);
     }
+}
+
+// How much of a complete, thinned list the compact array holds: the survivors are appended in list order, so those of
+// the leaves [0, L) fill its first slots exactly, L the first leaf whose survivors no longer fit (n when all do).  Returns
+// L; n_kept = survivors of the leaves before it.  A pixel's rounds test those from the array and go on in the list at leaf L.
+RT_DEV int beam_compact_prefix(const int32_t* cand, int n, int capacity, int& n_kept) {
+    int kept = 0, c = 0;
+    for (; c < n; c++) {
+        const int more = __popc((uint32_t)cand[3 * c + 2]);
+        if (kept + more > capacity) break;
+        kept += more;
+    }
+    n_kept = kept;
+    return c;
 }
 
 // A sample's search state over the instalments of its pixel's list.

@@ -86,6 +86,9 @@ constexpr size_t kStaticScratchBytes = kStaticOffOrder + (size_t)kStaticTiles * 
 // Address of that array on `device` (looked up once per device with that device current, then kept).
 hipError_t static_scratch(int device, void** ptr);
 // src and dst: packed dx*dy RGBA8 device images; tmp: dx*dy*3 float64
+#ifdef RT_WAVE_TIMES
+void debug_wave_times(unsigned long long* out, bool reset);  // diagnostics build: k_beam's persistent waves, start / end (100 MHz clock) / items each
+#endif
 #ifdef RT_VISIT_STATS
 void debug_packet_stats(unsigned long long* out8, bool reset);  // diagnostics build only
 void debug_trace_stats(unsigned long long* out32, bool reset);

@@ -1014,7 +1014,12 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     beam_cull_item32<PYR>(bt.f32, beam_state, beam_cand, beam_state + kBeamPixels * kBeamStateDwords, beam_compact, pass.block_px, p);
     if (p < pass.block_px) {
         const int32_t found = beam_state[p * kBeamStateDwords + 15];
-        if (!(found & 0x100)) beam_suffix_min(beam_cand + p * kBeamCands * 3, found & 0xff);
+        if (!(found & 0x100)) {
+            int n_kept = 0;
+            beam_state[p * kBeamStateDwords + 46] = beam_compact_prefix(beam_cand + p * kBeamCands * 3, found & 0xff, kBeamFacesMax, n_kept);
+            beam_state[p * kBeamStateDwords + 25] = n_kept;
+            beam_suffix_min(beam_cand + p * kBeamCands * 3, found & 0xff);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1046,8 +1051,11 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         const int32_t found = __builtin_amdgcn_readfirstlane(px_state[15]);
         const int beam_first = found & 0xff;
         const bool beam_long = (found & 0x100) != 0;
+        // a complete list: its first survivors from the compact array, then (seldom reached: the list is ordered by distance) the
+        // leaves from `beam_resume` on, face data from memory
         const int n_compact = __builtin_amdgcn_readfirstlane(px_state[25]);
-        const bool use_compact = !beam_long && n_compact <= kBeamFacesMax;  // else: the leaf list, face data from memory
+        const int beam_resume = __builtin_amdgcn_readfirstlane(px_state[46]);
+        const bool use_compact = !beam_long;
         const int32_t* const px_compact = beam_compact + pb * kBeamFacesMax * kBeamFaceDwords;
         const double beam_T = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[11]) << 32) |
                                                                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[10])));
@@ -1063,6 +1071,12 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         const double xd = (double)lx, yd = (double)y;
         const uint32_t ctr0 = (uint32_t)(y * pass.dx + lx);
         V3 acc = mk(0, 0, 0);
+#ifdef RT_VISIT_STATS
+        const long long px_t0 = clock64();
+        if (found != 0) RT_STAT(0, 1);                     // pixels that list something
+        if (beam_long) RT_STAT(5, 1);                      // ... whose list goes on beyond one instalment
+        if (!beam_long && beam_resume < beam_first) RT_STAT(6, 1);     // ... with more survivors than the compact array holds
+#endif
         for (int round = 0; round < rounds; round++) {
             const int k = (round << 6) + p;
             const bool traced = k < pass.sample_count;
@@ -1097,8 +1111,11 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
 #ifdef RT_VISIT_STATS
             const long long faces_t0 = clock64();
 #endif
-            if (use_compact) beam_test_compact<PYR>(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, bh);
-            else do {
+            if (use_compact) {
+                beam_test_compact<PYR>(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, bh);
+                if (beam_resume < beam_first)
+                    beam_test_prepared<PYR>(bt, o, d, fx, fy, fz, beam_T, px_cand + 3 * beam_resume, beam_first - beam_resume, true, kEps, sound, bh);
+            } else do {
                 int n = beam_first;
                 if (walking) {
 #ifdef RT_VISIT_STATS
@@ -1144,6 +1161,11 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
                 }
             }
         }
+#ifdef RT_VISIT_STATS
+        RT_STAT(9, clock64() - px_t0);                                       // cycles in the rounds of all pixels
+        if (beam_long) RT_STAT(8, clock64() - px_t0);                        // ... of the pixels with long lists
+        if (!beam_long && beam_resume < beam_first) RT_STAT(7, clock64() - px_t0);       // ... of those with too many survivors
+#endif
         // sum over the 64 lanes of the pixel, in the order k_primary adds them
         for (int off = 32; off > 0; off >>= 1) {
             acc.x += __shfl_xor(acc.x, off, 64);
@@ -1169,6 +1191,10 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
     uint32_t n_total = 0, n_left = 0, n_culled = 0;
     VisitCounts vc{0, 0};
+#ifdef RT_WAVE_TIMES
+    const unsigned long long wave_t0 = wall_clock64();
+    unsigned long long wave_items = 0;
+#endif
     // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
     auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
         const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
@@ -1206,7 +1232,17 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         const long long t_start = pass.cost ? clock64() : 0;
         beam_item<IMG, PYR>(sc, cam, pass, bt, film, v, sub, p, sc.stack_pairs, n_total, n_left, n_culled, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
+#ifdef RT_WAVE_TIMES
+        wave_items++;
+#endif
     }
+#ifdef RT_WAVE_TIMES
+    if (p == 0 && blockIdx.x < 8192) {
+        g_wave_times[3 * blockIdx.x] = wave_t0;
+        g_wave_times[3 * blockIdx.x + 1] = wall_clock64();
+        g_wave_times[3 * blockIdx.x + 2] = wave_items;
+    }
+#endif
     if (p == 0) {  // the tallies are per wave already
         Counters::Tally& t = counters->tally[blockIdx.x & (kTallyStripes - 1)];
         if (n_total) atomicAdd(&t.total, (unsigned long long)n_total);
@@ -2048,6 +2084,15 @@ void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf
     }
 }
 
+#ifdef RT_WAVE_TIMES
+void debug_wave_times(unsigned long long* out, bool reset) {  // out: 3 * 8192 values
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), 3 * 8192 * sizeof(unsigned long long));
+    if (reset) {
+        static const unsigned long long zero[3 * 8192] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_times), zero, sizeof(zero));
+    }
+}
+#endif
 #ifdef RT_VISIT_STATS
 void debug_packet_stats(unsigned long long* out8, bool reset) {  // out8: 16 values
     (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_packet_stats), 16 * sizeof(unsigned long long));

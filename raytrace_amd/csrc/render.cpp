@@ -839,6 +839,33 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     }
     if (int rc = read_counters()) return rc;
     if (sc->cancel.load()) return fail(RT_ERR_CANCELLED, "render cancelled");  // the film holds a frame nobody waits for any more
+#ifdef RT_WAVE_TIMES
+    {
+        {  // when the persistent waves of the last k_beam launch began and ended
+            std::vector<unsigned long long> wt(3 * 8192);
+            debug_wave_times(wt.data(), true);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            size_t n = 0;
+            for (size_t i = 0; i < 8192; i++)
+                if (wt[3 * i + 1]) { t0 = std::min(t0, wt[3 * i]); t1 = std::max(t1, wt[3 * i + 1]); n++; }
+            if (n) {
+                std::vector<double> ends, starts;
+                unsigned long long items_min = ~0ull, items_max = 0;
+                for (size_t i = 0; i < 8192; i++)
+                    if (wt[3 * i + 1]) {
+                        ends.push_back((double)(wt[3 * i + 1] - t0) * 1e-5);   // ms at 100 MHz
+                        starts.push_back((double)(wt[3 * i] - t0) * 1e-5);
+                        items_min = std::min(items_min, wt[3 * i + 2]); items_max = std::max(items_max, wt[3 * i + 2]);
+                    }
+                std::sort(ends.begin(), ends.end());
+                std::sort(starts.begin(), starts.end());
+                auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)(f * (double)(v.size() - 1))]; };
+                fprintf(stderr, "[rt] k_beam waves %zu: start (ms) median %.3f last %.3f; end (ms) first %.3f 10%% %.3f median %.3f 90%% %.3f 99%% %.3f last %.3f; items per wave %llu..%llu\n",
+                        n, q(starts, 0.5), starts.back(), ends.front(), q(ends, 0.1), q(ends, 0.5), q(ends, 0.9), q(ends, 0.99), ends.back(), items_min, items_max);
+            }
+        }
+    }
+#endif
 #ifdef RT_VISIT_STATS
     {
         unsigned long long ps[16];
@@ -847,9 +874,10 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
         fprintf(stderr, "[rt] packet walks %llu: per walk %.2f inner nodes, %.2f leaves, %.2f float32 face tests, %.2f float64 face tests, %.2f pops, %.2f pushes\n",
                 ps[0], ps[1] / w, ps[2] / w, ps[3] / w, ps[4] / w, ps[5] / w, ps[6] / w);
         if (getenv("RT_DEBUG_BEAM"))
-            fprintf(stderr, "[rt] pixel beams: %llu pixels walked, %.1f inner nodes and %.2f leaves listed each, %.2f %% with a list longer than one instalment (%llu instalments inside rounds); "
-                            "per round %.2f leaves looked at, %.2f float32 face tests, %.2f float64; beam walks %.1f %% of all round cycles\n",
-                    ps[0], ps[1] / w, ps[6] / w, 100.0 * ps[5] / w, ps[7], ps[2] / rounds, ps[3] / rounds, ps[4] / rounds, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0);
+            fprintf(stderr, "[rt] pixel beams: %llu pixels list faces; %llu of them (%.3f %%) have a list longer than one instalment and take %.2f %% of the cycles of all rounds, "
+                            "%llu (%.3f %%) have more survivors than the compact array holds and take %.2f %%; per round %.2f leaves looked at, %.2f float32 face tests, %.2f float64\n",
+                    ps[0], ps[5], 100.0 * ps[5] / w, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0, ps[6], 100.0 * ps[6] / w, ps[9] ? 100.0 * ps[7] / ps[9] : 0.0,
+                    ps[2] / rounds, ps[3] / rounds, ps[4] / rounds);
         fprintf(stderr, "[rt] wave rounds %llu: %.0f cycles each on average; walks %.0f cycles each (%.0f of them in leaves), %.1f %% of all round cycles\n",
                 ps[10], ps[9] / rounds, ps[8] / w, ps[11] / w, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0);
         unsigned long long ts[64];
