@@ -31,6 +31,7 @@ struct PassDesc {
     int32_t cull_pixels;            // pixel beams: a pixel whose bundle of rays misses the mesh is settled without generating its rays (they are counted)
     const int32_t* order;
     uint32_t* cost;
+    uint32_t* flag;                 // pixel beams: set, flag[tile] becomes 1 when a pixel of the tile lists more leaves than one instalment holds (its rounds run many times longer than others': the host then schedules such tiles first)
     uint32_t queue_off[8], queue_len[8];
 };
 

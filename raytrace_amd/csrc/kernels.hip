@@ -1004,7 +1004,10 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
             if (setup(lx, pass.dy - 1 - row, st)) {
                 found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f);
 #endif
-                if (st[12] != kFastEmpty) found |= 0x100;  // the list goes on: this pixel's rounds walk it in instalments
+                if (st[12] != kFastEmpty) {  // the list goes on: this pixel's rounds walk it in instalments
+                    found |= 0x100;
+                    if (pass.flag) pass.flag[v] = 1u;
+                }
             }
         }
         st[15] = found;

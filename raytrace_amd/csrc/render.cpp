@@ -54,6 +54,8 @@ struct WorkBuffers {
     std::string order_key;
     bool order_valid = false;
     uint32_t queue_off[8] = {}, queue_len[8] = {};
+    std::vector<int32_t> host_order;  // the schedule as uploaded
+    bool order_refined = false;       // the first pixel-beam launch that ran from it has told which tiles hold pixels with long lists, and they have moved to the front
     uint64_t culled_pixels = 0;  // pixels of the tiles the schedule leaves out (outside the screen bounds of the scene)
     bool is_static = false;      // the buffers live in the library's static scratch: nothing to allocate, grow or free
 };
@@ -191,6 +193,8 @@ int ensure_work(const rt_scene* sc, Replica& rep, uint64_t want_paths) {
         std::swap(w->order_tiles, old->order_tiles);
         std::swap(w->order_key, old->order_key);
         std::swap(w->order_valid, old->order_valid);
+        std::swap(w->host_order, old->host_order);
+        std::swap(w->order_refined, old->order_refined);
         std::swap(w->culled_pixels, old->culled_pixels);
         for (int k = 0; k < 8; k++) { std::swap(w->queue_off[k], old->queue_off[k]); std::swap(w->queue_len[k], old->queue_len[k]); }
         destroy_work(old);
@@ -421,6 +425,25 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& ge
     }
     HIP_TRY(hipMemcpyAsync(w.tile_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));  // `order` goes out of scope
+    w.host_order = std::move(order);
+    w.order_refined = false;
+    return RT_OK;
+}
+
+// After the first pixel-beam launch that ran from the schedule: the tiles it flagged (a pixel whose bundle of rays grazes the
+// mesh lists more leaves than one instalment holds, and each of its rounds then walks the tree again: milliseconds for one
+// pixel) move to the front of their queues, so that no wave starts on one of them when the others are about to finish.
+// Measured on the 4K scan: the last wave of a launch ended 2.1 ms after the 99th percentile (78.4 against 76.3 ms).
+int refine_tile_order(WorkBuffers& w, int64_t tiles_total, hipStream_t stream) {
+    std::vector<uint32_t> flag((size_t)tiles_total);
+    HIP_TRY(hipMemcpyAsync(flag.data(), w.tile_cost, flag.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < 8; k++)
+        std::stable_partition(w.host_order.begin() + w.queue_off[k], w.host_order.begin() + w.queue_off[k] + w.queue_len[k],
+                              [&](int32_t t) { return flag[(size_t)t] != 0; });
+    HIP_TRY(hipMemcpyAsync(w.tile_order, w.host_order.data(), w.host_order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    w.order_refined = true;
     return RT_OK;
 }
 
@@ -679,6 +702,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
         }
         if (pilot) s_count = std::min(s_count, kPilotSamples);
         else plan(s_count);
+        bool learned = false;  // a launch of this pass wrote tile flags (pixel beams)
         for (int64_t t0 = 0; t0 < tiles_total; t0 += tiles_per_launch) {
             if (sc->cancel.load()) {
                 (void)hipStreamSynchronize(stream);
@@ -716,6 +740,12 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
             const bool whole = t0 == 0 && nt == tiles_total;
             pass.order = (want_order && w.order_valid && whole) ? w.tile_order : nullptr;
             pass.cost = (pilot && whole) ? w.tile_cost : nullptr;
+            const bool learn = beam && pass.order && !pass.cost && !w.order_refined && !w.host_order.empty() && !getenv("RT_NO_ORDER_REFINE");
+            pass.flag = learn ? w.tile_cost : nullptr;
+            if (learn) {
+                HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
+                learned = true;
+            }
             for (int k = 0; k < 8; k++) { pass.queue_off[k] = w.queue_off[k]; pass.queue_len[k] = w.queue_len[k]; }
             if (pass.cost) HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
             if (int rc = reset_cursors()) return rc;
@@ -823,6 +853,8 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 cur = 1 - cur;
             }
         }
+        if (learned)
+            if (int rc = refine_tile_order(w, tiles_total, stream)) return rc;
         if (pilot) {
             Occupancy occ;
             TileGeometry geo{o->dx, o->dy, pass.groups_x, pass.local_rows, pass.band_rank, pass.band_world, nullptr};
