@@ -89,14 +89,14 @@ RT_DEV bool face32_rejects_dirs(const BeamFace32& t, float cx, float cy, float c
 #endif
 constexpr int kBeamFacesMax = RT_BEAM_FACES;
 constexpr int kBeamFaceDwords = 16;
-constexpr int kBeamCullDwords = 32;  // beam_cull_item32's own LDS: prefix sums of the list lengths (9), survivors per pixel (8)
+constexpr int kBeamCullDwords = (2 * kBeamPixels + 1 + 3) & ~3;  // beam_cull_item32's own LDS: prefix sums of the list lengths (kBeamPixels + 1), survivors per pixel (kBeamPixels); a multiple of 4 keeps the compact entries 16-byte aligned
 
 // beam_cull_item (dev_bvh.h) on the prepared faces: kBeamLeafFaces lanes per listed leaf, one per face, each testing its
 // face against the bundle of the leaf's pixel; the survivors become the leaf's mask and are appended, in list order, to the
 // pixel's compact array (entry 12 holds the position of the face's leaf in the list until beam_patch_distances has run).
 // beam_state[j * kBeamStateDwords + 25] receives the number of survivors of pixel j.  Must be entered by all 64 lanes.
 template <bool PYR>
-RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32_t* beam_cand, int32_t* prefix, int32_t* compact, int n_px, int lane) {
+RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32_t* beam_cand, int cands, int32_t* prefix, int32_t* compact, int n_px, int lane) {
     int len = 0;
     if (lane < n_px) {
         const int32_t v = beam_state[lane * kBeamStateDwords + 15];
@@ -108,7 +108,7 @@ RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32
         const int o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
-    int32_t* const count = prefix + 9;
+    int32_t* const count = prefix + kBeamPixels + 1;
     if (lane < kBeamPixels) {
         prefix[lane + 1] = incl;
         count[lane] = 0;
@@ -129,7 +129,7 @@ RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32
             for (int k = 1; k < kBeamPixels; k++)
                 if (s >= prefix[k]) j = k;
             at = s - prefix[j];
-            entry = beam_cand + (j * kBeamCands + at) * 3;
+            entry = beam_cand + (j * cands + at) * 3;
             const uint32_t code = (uint32_t)~entry[0];
             if (q <= (int)(code & (uint32_t)(kBeamLeafFaces - 1))) {
                 const int32_t* st = beam_state + j * kBeamStateDwords;
@@ -179,12 +179,12 @@ RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32
 
 // After beam_suffix_min: every compact entry takes the entry distance its leaf now carries (a suffix minimum, so the
 // distances of a pixel's entries never decrease and a round can stop at the first one beyond its hit).
-RT_DEV void beam_patch_distances(const int32_t* beam_state, const int32_t* beam_cand, int32_t* compact, int n_px, int lane) {
+RT_DEV void beam_patch_distances(const int32_t* beam_state, const int32_t* beam_cand, int cands, int32_t* compact, int n_px, int lane) {
     for (int k = lane; k < n_px * kBeamFacesMax; k += 64) {
         const int j = k / kBeamFacesMax, i = k - j * kBeamFacesMax;
         if (i < beam_state[j * kBeamStateDwords + 25]) {
             int32_t* e = compact + k * kBeamFaceDwords;
-            e[12] = beam_cand[(j * kBeamCands + e[12]) * 3 + 1];
+            e[12] = beam_cand[(j * cands + e[12]) * 3 + 1];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -879,12 +879,10 @@ RT_DEV bool mesh_collide_packet(const DScene& sc, const DMesh& m, const Ray& r, 
 #define RT_BEAM_PIXELS 4
 #endif
 constexpr int kBeamPixels = RT_BEAM_PIXELS;      // pixels of a work item at most (one lane walks each)
-#ifndef RT_BEAM_CANDS
-#define RT_BEAM_CANDS 64
-#endif
-// leaves listed per pixel at a time; a longer list is produced in instalments.  The lists of a wave's pixels live in LDS, which
-// caps the occupancy: measured on the 4K scan, pixels x leaves = 8 x 48: 59.5 Grays/s, 8 x 64: 63.0, 8 x 80: 54.0, 4 x 96: 63.9, 4 x 128: 63.6, 4 x 192: 54.2
-constexpr int kBeamCands = RT_BEAM_CANDS;
+// Leaves listed per pixel at a time (`cands`, at most kBeamCandsMax: PassDesc::beam_cands); a longer list is produced in instalments.
+// The lists of a wave's pixels live in LDS, which caps the occupancy: the host sizes them so that the workgroups a CU's registers
+// allow also fit its LDS (launch_beam).
+constexpr int kBeamCandsMax = 64;
 constexpr int kBeamStateDwords = 48;
 constexpr int kBeamLeafFaces = 1 << RT_BEAM_LEAF_BITS;             // faces a leaf of the beams' tree holds at most
 constexpr uint32_t kBeamLeafMask = (1u << kBeamLeafFaces) - 1u;  // one bit per face of such a leaf
@@ -1057,11 +1055,11 @@ RT_DEV void beam_setup_pyr(const DCamera& cam, V3 org, int32_t dx_img, int32_t d
     state[14] = 0;
 }
 
-// One instalment of a pixel's walk: up to kBeamCands leaves, (reference, entry distance, face mask) triples in cand.  The
+// One instalment of a pixel's walk: up to `cands` leaves, (reference, entry distance, face mask) triples in cand.  The
 // walk is over when state[12] == kFastEmpty afterwards.  stack: this lane's own 2 * cap dwords.  `scale` turns the entry
 // parameter into a distance no ray of the bundle undercuts (1 for parallel rays).
 template <typename Slabs>
-RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int cap, int32_t* cand, bool& overflow, float scale
+RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int cap, int32_t* cand, int cands, bool& overflow, float scale
 #ifdef RT_VISIT_STATS
                      , uint32_t& steps
 #endif
@@ -1109,7 +1107,7 @@ RT_DEV int beam_fill(const FastNode* nodes, int32_t* state, int32_t* stack, int 
                 pop();
             }
         } else {
-            if (count == kBeamCands) break;  // the list is full: the next instalment resumes at this leaf
+            if (count == cands) break;  // the list is full: the next instalment resumes at this leaf
             cand[3 * count] = cur;
             cand[3 * count + 1] = __float_as_int(cur_tn * scale);
             cand[3 * count + 2] = (int32_t)(kBeamLeafMask >> (kBeamLeafFaces - 1 - (int)((uint32_t)~cur & (uint32_t)(kBeamLeafFaces - 1))));  // every face of the leaf, until beam_cull_item32 has looked

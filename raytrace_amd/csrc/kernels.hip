@@ -959,13 +959,13 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
     f32[i] = q;
 }
 
-// One work item: pass.block_px (at most kBeamPixels) consecutive pixels of tile v, all samples of the pass.  Dynamic LDS:
+// One work item: block_px (at most kBeamPixels) consecutive pixels of tile v, all samples of the pass.  Dynamic LDS:
 // the walking lanes' stacks (lane j: 2 * cap dwords at j * 2 * cap), then at pass.beam_offset the lists (kBeamPixels x
-// kBeamCands triples), the walks' states, kBeamCullDwords for beam_cull_item32 and the pixels' compact face arrays.
+// pass.beam_cands triples), the walks' states, kBeamCullDwords for beam_cull_item32 and the pixels' compact face arrays.
 // PYR: the rays come from one point (pinhole camera; focusable camera without aperture) instead of sharing a direction.
 template <bool IMG, bool PYR>
 RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const BeamTables& bt, double* __restrict__ film, long long v,
-                      uint32_t sub, int p, int cap, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, VisitCounts& vc) {
+                      uint32_t sub, int block_px, int p, int cap, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, VisitCounts& vc) {
     const int rounds = (pass.sample_count + 63) >> 6;
     const int64_t tile = pass.tile_begin + v;
     const int64_t group = tile >> 6;
@@ -974,7 +974,8 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     const int tile_y = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8;
     const double inv_dx = 1.0 / (double)pass.dx, inv_dy = 1.0 / (double)pass.dy;  // for div_by: the divisions of render.go:202-210
     int32_t* const beam_cand = dyn_lds + pass.beam_offset;
-    int32_t* const beam_state = beam_cand + kBeamPixels * kBeamCands * 3;
+    const int cands = pass.beam_cands;
+    int32_t* const beam_state = beam_cand + kBeamPixels * cands * 3;
     int32_t* const beam_compact = beam_state + kBeamPixels * kBeamStateDwords + kBeamCullDwords;
     const DMesh& m = sc.meshes[sc.nodes[0].index];
     const FastNode* const tree = sc.fast_nodes + m.beam_off;
@@ -989,9 +990,9 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         return beam_setup(cam, pass.dx, pass.dy, m, lx, y, st);
     };
     // lane j walks the bundle of pixel j of the item: the first instalment of its list, and whether there is more
-    if (p < pass.block_px) {
+    if (p < block_px) {
         int32_t* const st = beam_state + p * kBeamStateDwords;
-        const int pix = (int)sub * pass.block_px + p;
+        const int pix = (int)sub * block_px + p;
         const int lx = tile_x + (pix & 7), ly = tile_y + (pix >> 3);
         const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);
         int32_t found = 0;
@@ -999,10 +1000,10 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
 #ifdef RT_VISIT_STATS
             uint32_t steps = 0;
             if (setup(lx, pass.dy - 1 - row, st)) {
-                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f, steps);
+                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * cands * 3, cands, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f, steps);
 #else
             if (setup(lx, pass.dy - 1 - row, st)) {
-                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * kBeamCands * 3, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f);
+                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * cands * 3, cands, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f);
 #endif
                 if (st[12] != kFastEmpty) {  // the list goes on: this pixel's rounds walk it in instalments
                     found |= 0x100;
@@ -1014,19 +1015,19 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    beam_cull_item32<PYR>(bt.f32, beam_state, beam_cand, beam_state + kBeamPixels * kBeamStateDwords, beam_compact, pass.block_px, p);
-    if (p < pass.block_px) {
+    beam_cull_item32<PYR>(bt.f32, beam_state, beam_cand, cands, beam_state + kBeamPixels * kBeamStateDwords, beam_compact, block_px, p);
+    if (p < block_px) {
         const int32_t found = beam_state[p * kBeamStateDwords + 15];
         if (!(found & 0x100)) {
             int n_kept = 0;
-            beam_state[p * kBeamStateDwords + 46] = beam_compact_prefix(beam_cand + p * kBeamCands * 3, found & 0xff, kBeamFacesMax, n_kept);
+            beam_state[p * kBeamStateDwords + 46] = beam_compact_prefix(beam_cand + p * cands * 3, found & 0xff, kBeamFacesMax, n_kept);
             beam_state[p * kBeamStateDwords + 25] = n_kept;
-            beam_suffix_min(beam_cand + p * kBeamCands * 3, found & 0xff);
+            beam_suffix_min(beam_cand + p * cands * 3, found & 0xff);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    beam_patch_distances(beam_state, beam_cand, beam_compact, pass.block_px, p);
+    beam_patch_distances(beam_state, beam_cand, cands, beam_compact, block_px, p);
 
     // what every hit of the item samples (wave-uniform: scalar loads)
     const rt_material& mat = sc.materials[sc.nodes[0].material];
@@ -1040,9 +1041,9 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
     }
     const V3 d_all = ld3(cam.dir);  // every ray of an orthographic camera has the camera's direction (camera_orthographic.go:44)
     const bool d_sound = PYR || !bad3(d_all);
-    for (int pb = 0; pb < pass.block_px; pb++) {
+    for (int pb = 0; pb < block_px; pb++) {
         // all 64 lanes are on this pixel: everything about it is wave-uniform
-        const int pix = (int)sub * pass.block_px + pb;
+        const int pix = (int)sub * block_px + pb;
         const int lx = tile_x + (pix & 7);
         const int ly = tile_y + (pix >> 3);
         const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);  // image row, 0 = top
@@ -1050,7 +1051,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         const int y = pass.dy - 1 - row;  // the reference's y grows upward (render.go:195)
         const uint32_t pixel = (uint32_t)(row * pass.dx + lx);
         int32_t* const px_state = beam_state + pb * kBeamStateDwords;
-        int32_t* const px_cand = beam_cand + pb * kBeamCands * 3;
+        int32_t* const px_cand = beam_cand + pb * cands * 3;
         const int32_t found = __builtin_amdgcn_readfirstlane(px_state[15]);
         const int beam_first = found & 0xff;
         const bool beam_long = (found & 0x100) != 0;
@@ -1123,9 +1124,9 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
                 if (walking) {
 #ifdef RT_VISIT_STATS
                     uint32_t again = 0;
-                    if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, vc.overflow, scale, again);
+                    if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, cands, vc.overflow, scale, again);
 #else
-                    if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, vc.overflow, scale);
+                    if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, cands, vc.overflow, scale);
 #endif
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -1198,10 +1199,23 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     const unsigned long long wave_t0 = wall_clock64();
     unsigned long long wave_items = 0;
 #endif
-    // Draws the next item of one queue: tile number (or -1 when that queue is exhausted) and sub-block.
-    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
+    // Draws the next item of one queue: tile number (or -1 when that queue is exhausted), sub-block and pixels of the item.
+    // The first queue_flagged[owner] tiles of a scheduled queue hold pixels that take milliseconds each (refine_tile_order):
+    // they are handed out a pixel at a time, so that no wave gets several of those in one item.
+    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out, uint32_t& px_out) {
         const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
-        const uint32_t idx = item / n_sub;
+        const uint32_t fine = pass.order ? pass.queue_flagged[owner] * 64u : 0u;  // items of one pixel at the front of the queue
+        uint32_t idx;
+        if (item < fine) {
+            idx = item >> 6;
+            sub_out = item & 63u;
+            px_out = 1u;
+        } else {
+            const uint32_t rest = item - fine;
+            idx = (fine >> 6) + rest / n_sub;
+            sub_out = rest - (rest / n_sub) * n_sub;
+            px_out = (uint32_t)pass.block_px;
+        }
         long long cand = -1;
         if (pass.order) {
             if (idx < pass.queue_len[owner]) cand = pass.order[pass.queue_off[owner] + idx];
@@ -1209,22 +1223,22 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
             cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
         }
         tile_out = (cand >= 0 && cand < n_tiles) ? cand : -1;
-        sub_out = item - idx * n_sub;
     };
     // the item after the current one is drawn while the current one is traced (the atomic's round trip is off the critical path)
     long long ahead_v = -1;
-    uint32_t ahead_sub = 0;
-    if (p == 0) draw(xcd, ahead_v, ahead_sub);
+    uint32_t ahead_sub = 0, ahead_px = 1;
+    if (p == 0) draw(xcd, ahead_v, ahead_sub, ahead_px);
     for (;;) {
         long long v = -1;
-        uint32_t sub = 0;
+        uint32_t sub = 0, px = 1;
         if (p == 0) {
             if (ahead_v >= 0) {
                 v = ahead_v;
                 sub = ahead_sub;
-                draw(xcd, ahead_v, ahead_sub);
+                px = ahead_px;
+                draw(xcd, ahead_v, ahead_sub, ahead_px);
             } else {  // own queue exhausted (cursors only grow): take from the other XCDs' queues
-                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub);
+                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub, px);
             }
         }
         // lane 0's values, as scalars: everything derived from them (the item's pixels) stays in scalar registers
@@ -1232,8 +1246,9 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         v = (long long)(((unsigned long long)(uint32_t)v_hi << 32) | (uint32_t)v_lo);
         if (v < 0) break;
         sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
+        px = (uint32_t)__builtin_amdgcn_readfirstlane((int)px);
         const long long t_start = pass.cost ? clock64() : 0;
-        beam_item<IMG, PYR>(sc, cam, pass, bt, film, v, sub, p, sc.stack_pairs, n_total, n_left, n_culled, vc);
+        beam_item<IMG, PYR>(sc, cam, pass, bt, film, v, sub, (int)px, p, sc.stack_pairs, n_total, n_left, n_culled, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
 #ifdef RT_WAVE_TIMES
         wave_items++;
@@ -1971,28 +1986,29 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     // the stacks of the kBeamPixels walking lanes, a (reference, distance) pair per level each; behind them the lists, the
     // walks' states and beam_cull_item32's prefix sums
     size_t lds = (size_t)kBeamPixels * 2 * sc.stack_pairs * sizeof(int32_t);
-    lds = (lds + 7) & ~(size_t)7;
+    lds = (lds + 15) & ~(size_t)15;
     PassDesc pd = pass;
     pd.acc_offset = 0;
     pd.beam_offset = (int32_t)(lds / sizeof(int32_t));
-    lds += ((size_t)kBeamPixels * (kBeamCands * 3 + kBeamStateDwords + kBeamFacesMax * kBeamFaceDwords) + kBeamCullDwords) * sizeof(int32_t);
+    // Leaves per list: what is left of a workgroup's share of the CU's LDS.  The hardware hands LDS out in pieces of 1280 bytes
+    // (measured: with 7696 bytes per workgroup 18 of them are resident on a CU, with 7600 bytes the 20 that the registers allow;
+    // 18 instead of 20 cost 5 % on the 4K scan), so the share is the largest multiple of that which lets all workgroups in.
+    const size_t per_cu = 160 * 1024, piece = 1280, groups = (size_t)RT_BEAM_WAVES * 4;
+    const size_t share = per_cu / groups / piece * piece;
+    const size_t fixed = ((size_t)kBeamPixels * (kBeamStateDwords + kBeamFacesMax * kBeamFaceDwords) + kBeamCullDwords) * sizeof(int32_t);
+    const size_t per_leaf = (size_t)kBeamPixels * 3 * sizeof(int32_t);
+    int cands = 16;  // (a tree so deep that even this does not fit costs occupancy, nothing else)
+    if (share > lds + fixed + 16 * per_leaf) cands = (int)std::min<size_t>(kBeamCandsMax, (share - lds - fixed) / per_leaf);
+    pd.beam_cands = cands;
+    lds += fixed + (size_t)cands * per_leaf;
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);
         const unsigned waves = std::min(resident, (tiles + 7u) & ~7u);
         hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), lds, s, sc, cam, pd, counters, bt, film);
     };
-    // Waves per SIMD: RT_BEAM_WAVES (5: 96 registers and 120 B of scratch per lane) for a whole frame, one fewer (128 registers, no
-    // scratch) for a small share of one, whose short launch gains nothing from the fifth wave.  Measured on the 4K scan at 1024
-    // samples, 4 against 5 waves: whole frame 81.9 / 80.8 ms, a quarter 21.9 / 21.7, an eighth 11.6 / 12.8.
-    const bool few = pass.n_pixels < 1500000;
-    if (few) {
-        if (bt.pyramid) { if (bt.image) go(k_beam<true, true, RT_BEAM_WAVES - 1>); else go(k_beam<false, true, RT_BEAM_WAVES - 1>); }
-        else { if (bt.image) go(k_beam<true, false, RT_BEAM_WAVES - 1>); else go(k_beam<false, false, RT_BEAM_WAVES - 1>); }
-    } else {
-        if (bt.pyramid) { if (bt.image) go(k_beam<true, true, RT_BEAM_WAVES>); else go(k_beam<false, true, RT_BEAM_WAVES>); }
-        else { if (bt.image) go(k_beam<true, false, RT_BEAM_WAVES>); else go(k_beam<false, false, RT_BEAM_WAVES>); }
-    }
+    if (bt.pyramid) { if (bt.image) go(k_beam<true, true, RT_BEAM_WAVES>); else go(k_beam<false, true, RT_BEAM_WAVES>); }
+    else { if (bt.image) go(k_beam<true, false, RT_BEAM_WAVES>); else go(k_beam<false, false, RT_BEAM_WAVES>); }
     return true;
 }
 

@@ -53,7 +53,7 @@ struct WorkBuffers {
     size_t order_tiles = 0;
     std::string order_key;
     bool order_valid = false;
-    uint32_t queue_off[8] = {}, queue_len[8] = {};
+    uint32_t queue_off[8] = {}, queue_len[8] = {}, queue_flagged[8] = {};
     std::vector<int32_t> host_order;  // the schedule as uploaded
     bool order_refined = false;       // the first pixel-beam launch that ran from it has told which tiles hold pixels with long lists, and they have moved to the front
     uint64_t culled_pixels = 0;  // pixels of the tiles the schedule leaves out (outside the screen bounds of the scene)
@@ -196,7 +196,7 @@ int ensure_work(const rt_scene* sc, Replica& rep, uint64_t want_paths) {
         std::swap(w->host_order, old->host_order);
         std::swap(w->order_refined, old->order_refined);
         std::swap(w->culled_pixels, old->culled_pixels);
-        for (int k = 0; k < 8; k++) { std::swap(w->queue_off[k], old->queue_off[k]); std::swap(w->queue_len[k], old->queue_len[k]); }
+        for (int k = 0; k < 8; k++) { std::swap(w->queue_off[k], old->queue_off[k]); std::swap(w->queue_len[k], old->queue_len[k]); std::swap(w->queue_flagged[k], old->queue_flagged[k]); }
         destroy_work(old);
     }
     rep.work = w;
@@ -427,6 +427,7 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& ge
     HIP_TRY(hipStreamSynchronize(stream));  // `order` goes out of scope
     w.host_order = std::move(order);
     w.order_refined = false;
+    for (int k = 0; k < 8; k++) w.queue_flagged[k] = 0;
     return RT_OK;
 }
 
@@ -438,9 +439,11 @@ int refine_tile_order(WorkBuffers& w, int64_t tiles_total, hipStream_t stream) {
     std::vector<uint32_t> flag((size_t)tiles_total);
     HIP_TRY(hipMemcpyAsync(flag.data(), w.tile_cost, flag.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    for (int k = 0; k < 8; k++)
-        std::stable_partition(w.host_order.begin() + w.queue_off[k], w.host_order.begin() + w.queue_off[k] + w.queue_len[k],
-                              [&](int32_t t) { return flag[(size_t)t] != 0; });
+    for (int k = 0; k < 8; k++) {
+        const auto first = w.host_order.begin() + w.queue_off[k];
+        const auto mid = std::stable_partition(first, first + w.queue_len[k], [&](int32_t t) { return flag[(size_t)t] != 0; });
+        w.queue_flagged[k] = (uint32_t)(mid - first);
+    }
     HIP_TRY(hipMemcpyAsync(w.tile_order, w.host_order.data(), w.host_order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     w.order_refined = true;
@@ -718,12 +721,13 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 int64_t want_rays = item_rays;
                 if (beam && !item_rays_fixed) {
                     // Pixel beams: a lane walks the tree for each pixel of an item, so more pixels keep more lanes busy in that
-                    // phase (kBeamPixels at most); against that an item should not run much longer than 4096 rays, and the fewer
-                    // items a resident wave gets the longer the chip waits for the last ones.  Measured with k_beam on the 4K scan
-                    // at 1024 samples (ms per frame share, items of 1 / 2 / 4 pixels): whole frame 100.6 / 89.7 / 82.0, a quarter of
-                    // it 25.9 / 22.5 / 21.7, an eighth 13.6 / 11.6 / 14.6.
+                    // phase (kBeamPixels at most); against that, the fewer items a resident wave gets the longer the chip waits for
+                    // the last ones.  (The pixels that take milliseconds each are handed out one at a time whatever this says, once
+                    // the schedule knows them: refine_tile_order.)  Measured with k_beam at 1024 samples, ms per launch with items of
+                    // 1 / 2 / 4 pixels: the 4K scan frame 97.2 / 81.2 / 73.3, a quarter of it 24.7 / 20.6 / 18.8, an eighth 12.8 / 10.7 / 9.7;
+                    // the same scene at 1920x1080 29.3 / 25.5 / 23.8, a quarter of that 7.7 / 6.8 / 6.8, an eighth 5.6 / 5.1 / 5.8.
                     const int64_t share_px = tiles_total * 64;
-                    int64_t px = share_px >= 1500000 ? 4 : (share_px >= 600000 ? 2 : 1);
+                    int64_t px = share_px >= 400000 ? 4 : (share_px >= 50000 ? 2 : 1);
                     px = std::min<int64_t>(px, std::max<int64_t>(1, 4096 / s_count));
                     px = std::max<int64_t>(px, std::min<int64_t>(8, 1024 / std::max(1, s_count)));
                     while (px & (px - 1)) px &= px - 1;  // down to a power of two
@@ -746,7 +750,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
                 learned = true;
             }
-            for (int k = 0; k < 8; k++) { pass.queue_off[k] = w.queue_off[k]; pass.queue_len[k] = w.queue_len[k]; }
+            for (int k = 0; k < 8; k++) { pass.queue_off[k] = w.queue_off[k]; pass.queue_len[k] = w.queue_len[k]; pass.queue_flagged[k] = w.order_refined ? w.queue_flagged[k] : 0; }
             if (pass.cost) HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
             if (int rc = reset_cursors()) return rc;
             EventPair* ev = nullptr;
@@ -892,8 +896,10 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 std::sort(ends.begin(), ends.end());
                 std::sort(starts.begin(), starts.end());
                 auto q = [&](const std::vector<double>& v, double f) { return v[(size_t)(f * (double)(v.size() - 1))]; };
-                fprintf(stderr, "[rt] k_beam waves %zu: start (ms) median %.3f last %.3f; end (ms) first %.3f 10%% %.3f median %.3f 90%% %.3f 99%% %.3f last %.3f; items per wave %llu..%llu\n",
-                        n, q(starts, 0.5), starts.back(), ends.front(), q(ends, 0.1), q(ends, 0.5), q(ends, 0.9), q(ends, 0.99), ends.back(), items_min, items_max);
+                size_t late = 0;
+                for (double t : starts) late += t > 0.5 * ends.back();
+                fprintf(stderr, "[rt] k_beam waves %zu (%zu of them started in the second half of the launch: not resident before): start (ms) median %.3f last %.3f; end (ms) first %.3f 10%% %.3f median %.3f 90%% %.3f 99%% %.3f last %.3f; items per wave %llu..%llu\n",
+                        n, late, q(starts, 0.5), starts.back(), ends.front(), q(ends, 0.1), q(ends, 0.5), q(ends, 0.9), q(ends, 0.99), ends.back(), items_min, items_max);
             }
         }
     }
