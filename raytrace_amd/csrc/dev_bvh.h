@@ -882,7 +882,10 @@ constexpr int kBeamPixels = RT_BEAM_PIXELS;      // pixels of a work item at mos
 // Leaves listed per pixel at a time (`cands`, at most kBeamCandsMax: PassDesc::beam_cands); a longer list is produced in instalments.
 // The lists of a wave's pixels live in LDS, which caps the occupancy: the host sizes them so that the workgroups a CU's registers
 // allow also fit its LDS (launch_beam).
-constexpr int kBeamCandsMax = 64;
+#ifndef RT_BEAM_CANDS_MAX
+#define RT_BEAM_CANDS_MAX 80
+#endif
+constexpr int kBeamCandsMax = RT_BEAM_CANDS_MAX;  // (a list's length travels in eight bits)
 constexpr int kBeamStateDwords = 48;
 constexpr int kBeamLeafFaces = 1 << RT_BEAM_LEAF_BITS;             // faces a leaf of the beams' tree holds at most
 constexpr uint32_t kBeamLeafMask = (1u << kBeamLeafFaces) - 1u;  // one bit per face of such a leaf
