@@ -447,6 +447,11 @@ int refine_tile_order(WorkBuffers& w, int64_t tiles_total, hipStream_t stream) {
     HIP_TRY(hipMemcpyAsync(w.tile_order, w.host_order.data(), w.host_order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     w.order_refined = true;
+    if (std::getenv("RT_DEBUG")) {
+        uint32_t n = 0;
+        for (int k = 0; k < 8; k++) n += w.queue_flagged[k];
+        fprintf(stderr, "[rt] tile schedule refined: %u tiles hold pixels with long lists\n", n);
+    }
     return RT_OK;
 }
 
@@ -744,7 +749,9 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
             const bool whole = t0 == 0 && nt == tiles_total;
             pass.order = (want_order && w.order_valid && whole) ? w.tile_order : nullptr;
             pass.cost = (pilot && whole) ? w.tile_cost : nullptr;
-            const bool learn = beam && pass.order && !pass.cost && !w.order_refined && !w.host_order.empty() && !getenv("RT_NO_ORDER_REFINE");
+            // (a launch of under 134 M rays -- a millisecond -- is over before the flags could repay their trip to the host and back)
+            const bool learn = beam && pass.order && !pass.cost && !w.order_refined && !w.host_order.empty() && nt * 64 * (int64_t)s_count >= ((int64_t)1 << 27) &&
+                               !getenv("RT_NO_ORDER_REFINE");
             pass.flag = learn ? w.tile_cost : nullptr;
             if (learn) {
                 HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));

@@ -94,6 +94,31 @@ def test_long_lists_and_odd_views(ob, monkeypatch, view):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, view
 
 
+def test_tiles_with_long_lists_first_and_a_pixel_at_a_time(monkeypatch):
+    """A sheet seen along its plane at 512 x 512 x 512 samples: many pixels list more leaves than a list holds, and the launch
+    is large enough (2^27 rays) for the library to learn which tiles hold them and to schedule those first, a pixel per work
+    item.  Frames rendered from the refined schedule, from the plain one (RT_NO_ORDER_REFINE=1) and by the packet walk must
+    be the same film, number for number: a pixel's sum is one wave's, added in one order, however the items are cut."""
+    from raytrace_amd import _lib
+    lib = _lib.load()
+    cam = phys.OrthographicCamera(LookFrom=(3.0, 0.0, 0.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0), FOVHeight=0.5, FOVWidth=2.2)
+    tex = phys.TextureCheckerboard(phys.TextureUniform((0.9, 0.3, 0.2)), phys.TextureUniform((0.1, 0.5, 0.9)), 40.0)
+    sc = phys.Scene(Camera=[cam], Node=[phys.Node("sheet", phys.NewMesh(grid_mesh()), phys.Emitter(tex))],
+                    RenderOptions=phys.RenderOptions(3, 512, 4, 512, 512))
+    films = {}
+    for name, env in (("refined", {}), ("plain", {"RT_NO_ORDER_REFINE": "1"}), ("packet", {"RT_NO_BEAM": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with phys.DeviceScene(sc) as dev:
+            films[name] = _film(dev, lib, sc, frames=3)  # pilot + 510 samples; 512 samples, whose launch is the one that learns; the frame from the refined schedule
+        for k in env:
+            monkeypatch.delenv(k)
+    assert films["refined"][1] == films["plain"][1] == films["packet"][1]
+    assert films["refined"][1][1] < films["refined"][1][0]  # something is hit
+    assert np.array_equal(films["refined"][0], films["plain"][0])
+    assert np.array_equal(films["refined"][0], films["packet"][0])
+
+
 def test_tiny_and_degenerate_meshes(monkeypatch):
     # tilted: a mesh whose bounds have no thickness is never hit (AABB.hit rejects tmax <= tmin, shape.go:81-96)
     one = np.array([[[0.0, 0.0, 0.0, 0.0, 0.0], [1.0, 0.0, 0.2, 1.0, 0.0], [0.0, 1.0, 0.1, 0.0, 1.0]]])
@@ -107,7 +132,7 @@ def test_tiny_and_degenerate_meshes(monkeypatch):
         assert 0 < beam.Stats.RaysLeftScene < beam.Stats.TotalRays
 
 
-def _film(dev, lib, sc, band=(0, 1), spp=None):
+def _film(dev, lib, sc, band=(0, 1), spp=None, frames=2):
     import ctypes as C
     import torch
     from raytrace_amd import _lib
@@ -119,7 +144,7 @@ def _film(dev, lib, sc, band=(0, 1), spp=None):
     # Twice: the first frame of a (camera, frame, share, culling) combination on a handle spends its first two samples on a
     # pilot pass that records what the tiles cost, so its sums are added up as 2 + 62 samples; the frames after it, from the
     # schedule, as one pass of 64.  The same samples either way -- but "number for number" wants the same order of additions.
-    for _ in range(2):
+    for _ in range(frames):
         film.zero_()
         _lib.check(lib.rt_render_film(dev.handle, C.byref(cd), C.byref(ro), C.c_void_p(film.data_ptr()), C.byref(st)), lib)
     torch.cuda.synchronize()
