@@ -1054,7 +1054,15 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         int32_t* const px_cand = beam_cand + pb * cands * 3;
         const int32_t found = __builtin_amdgcn_readfirstlane(px_state[15]);
         const int beam_first = found & 0xff;
+#if defined(RT_KO_LONG_CODE)  // knock-out builds (wrong pictures): the pixels with long lists skipped, and the code of their rounds left out as well
+        if (found & 0x100) continue;
+        const bool beam_long = false;
+#elif defined(RT_KO_LONG)
+        if (found & 0x100) continue;
         const bool beam_long = (found & 0x100) != 0;
+#else
+        const bool beam_long = (found & 0x100) != 0;
+#endif
         // a complete list: its first survivors from the compact array, then (seldom reached: the list is ordered by distance) the
         // leaves from `beam_resume` on, face data from memory
         const int n_compact = __builtin_amdgcn_readfirstlane(px_state[25]);
