@@ -1,4 +1,6 @@
 #!/bin/bash
+# What k_beam's pixels are made of (diagnostics build raytrace_amd/variants/librt_hip_stats.so: tools/sweep_build.sh "stats -DRT_VISIT_STATS"):
+# pixels that list faces, those with lists beyond one instalment or more survivors than the compact array holds, and their share of the wave-time.
 cd "$(dirname "$0")/.."
 for W in 1 8; do
 echo "== W=$W"
