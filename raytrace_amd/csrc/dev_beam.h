@@ -51,7 +51,15 @@ RT_DEV bool face32_rejects_bundle(const BeamFace32& t, float ox, float oy, float
     const float slack = 1.0f + 1.0f / 65536.0f;  // the bounds themselves are rounded
     const float dU = (ex * fabsf(t.h[0]) + ey * fabsf(t.h[1]) + ez * fabsf(t.h[2])) * slack;
     const float dV = (ex * fabsf(t.g[0]) + ey * fabsf(t.g[1]) + ez * fabsf(t.g[2])) * slack;
-    return us + dU < t.neg_eu || vs + dV < t.neg_ev || (us - dU) + (vs - dV) > t.lim;
+    // U + V is linear in the origin too: its own bound is tighter than dU + dV (the rounding of the sums h + g is inside the slack's share of dU + dV)
+    const float dW = fminf((ex * fabsf(t.h[0] + t.g[0]) + ey * fabsf(t.h[1] + t.g[1]) + ez * fabsf(t.h[2] + t.g[2])) * slack + (dU + dV) * (1.0f / 65536.0f), dU + dV);
+    return us + dU < t.neg_eu || vs + dV < t.neg_ev || (us + vs) - dW > t.lim;
+}
+
+// The bundle's footprint on the image plane, centre (cu, cv) and half sizes (hu, hv) along the camera's axes (margins for the
+// rounding of both sides included), beside the face's extent along them.
+RT_DEV bool face32_beside_footprint(const BeamFace32& t, float cu, float cv, float hu, float hv) {
+    return t.umax < cu - hu || t.umin > cu + hu || t.vmax < cv - hv || t.vmin > cv + hv;
 }
 
 // Rays from one point: one ray's direction against a face prepared for that point.  The table's fields hold
@@ -137,7 +145,8 @@ RT_DEV void beam_cull_item32(const BeamFace32* faces, int32_t* beam_state, int32
                 t = faces[face];
                 if (PYR) keep = !face32_rejects_dirs(t, __int_as_float(st[19]), __int_as_float(st[20]), __int_as_float(st[21]), __int_as_float(st[22]),
                                                      __int_as_float(st[23]), __int_as_float(st[24]));
-                else keep = !face32_rejects_bundle(t, __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]), __int_as_float(st[19]),
+                else keep = !face32_beside_footprint(t, __int_as_float(st[26]), __int_as_float(st[27]), __int_as_float(st[28]), __int_as_float(st[29])) &&
+                            !face32_rejects_bundle(t, __int_as_float(st[16]), __int_as_float(st[17]), __int_as_float(st[18]), __int_as_float(st[19]),
                                                    __int_as_float(st[20]), __int_as_float(st[21]));
             }
         }

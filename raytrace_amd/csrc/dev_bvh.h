@@ -894,7 +894,7 @@ constexpr uint32_t kBeamLeafMask = (1u << kBeamLeafFaces) - 1u;  // one bit per 
 // p * i + a, of a max plane p * i + b), 6-8 i = 1 / direction, 9 t_lo (where the rays start, in the bundle's frame),
 // 10-11 T (float64: the frame starts at o + d * T), 12 cur, 13 sp, 14 entry distance of cur, 15 the caller's (length
 // of the list), 16-18 origin of the centre ray in that frame, 19-21 half-extent of the footprint (margins included),
-// 22-24 direction (float32).  25: survivors of the pixel's list (beam_cull_item32), then those of them that the compact array
+// 22-24 direction (float32); 26-29 the footprint along the camera's image axes: centre (2), half sizes (2).  25: survivors of the pixel's list (beam_cull_item32), then those of them that the compact array
 // holds; 46: the leaf at which the list goes on after them (beam_compact_prefix).
 // A pyramid of rays from one point (beam_setup_pyr) uses instead: 16-18 the point in the mesh frame, 19-21 the centre of the
 // box of its directions, 22-24 that box's half-widths, 26-43 per axis (1 / d_lo, 1 / d_hi and the four offsets of
@@ -938,6 +938,18 @@ RT_DEV bool beam_setup(const DCamera& cam, int32_t dx_img, int32_t dy_img, const
         state[16 + k] = __float_as_int(ocf);
         state[19 + k] = __float_as_int(ef);
         state[22 + k] = __float_as_int((float)cam.dir[k]);
+    }
+    {  // the footprint along the camera's image axes, about the mesh's centre: the origins are from + u A + v B with A in [a0, a1], B in [b0, b1]
+        const V3 rel = ld3(cam.from) - ld3(m.center);
+        const double ru = dot(rel, ld3(cam.u)), rv = dot(rel, ld3(cam.v));
+        const double cu = ru + 0.5 * (a0 + a1), cv = rv + 0.5 * (b0 + b1);
+        // + 2^-20 R: the float32 rounding of this centre and of the faces' extents (each below 2^-23 of a coordinate), u and v
+        // not exactly orthonormal, the reference's own tolerance of 1e-8 in the barycentric coordinates
+        const double slop = (double)m.radius * 9.5367431640625e-7 + 1e-12 * (fabs(ru) + fabs(rv) + fabs(a0) + fabs(a1) + fabs(b0) + fabs(b1));
+        state[26] = __float_as_int((float)cu);
+        state[27] = __float_as_int((float)cv);
+        state[28] = __float_as_int(up32(0.5 * fabs(a1 - a0) + slop));
+        state[29] = __float_as_int(up32(0.5 * fabs(b1 - b0) + slop));
     }
     const float t_lo = -up32(T);
     state[9] = __float_as_int(t_lo);

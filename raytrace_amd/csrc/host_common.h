@@ -83,7 +83,7 @@ struct Replica {
     // frame's camera direction differs from beam_dir)
     BeamTables beam{};
     int64_t beam_faces = 0;
-    double beam_key[3] = {0, 0, 0};  // what the tables were last filled for: a direction, or (beam.pyramid) a point
+    double beam_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // what the tables were last filled for: a direction and the camera's image axes u, v, or (beam.pyramid) a point
     bool beam_key_valid = false;
 };
 

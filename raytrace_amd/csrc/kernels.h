@@ -63,7 +63,7 @@ void launch_primary(const DScene& sc, const DCamera* cam, const PassDesc& pass, 
 int beam_pixels_max();
 // The pixel-beam kernel (k_beam) and the pre-pass that fills its tables for a camera direction (dev_beam.h).  launch_beam
 // returns false when the pass cannot run on it (fewer than 64 lanes per pixel, larger items, one sample per pixel).
-void launch_beam_prepare(const DScene& sc, int64_t n_faces, bool pyr, const double key[3], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s);  // key: the direction, or (pyr) the point
+void launch_beam_prepare(const DScene& sc, int64_t n_faces, bool pyr, const double key[9], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s);  // key: the direction and the camera's two image axes, or (pyr) the point and zeros
 bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Counters* counters, const BeamTables& bt, double* film, hipStream_t s);
 size_t beam_table_bytes(int64_t n_faces, size_t* off_f64, size_t* off_uv);  // one allocation: BeamFace32[n], then BeamFace64[n], then 6 doubles per face
 // tracePath for the first n.n[s] rays of every stripe s of rays[in]: closest hit, Material.Resolve, children appended to

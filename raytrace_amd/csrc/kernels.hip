@@ -880,7 +880,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
 
 // The tables of dev_beam.h for direction (dx, dy, dz), or (PYR) for rays from the point (dx, dy, dz): one thread per face, leaf order.
 template <bool PYR>
-__global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, double dy, double dz, BeamFace32* __restrict__ f32,
+__global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, double dy, double dz, V3 axis_u, V3 axis_v, BeamFace32* __restrict__ f32,
                                                          BeamFace64* __restrict__ f64, double* __restrict__ uv) {
     const DMesh& m = sc.meshes[sc.nodes[0].index];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -916,6 +916,8 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
             const float reach = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + m.radius;
             const float err_d = kErr * 1.01f, err_r = err_d * reach;
             r.neg_eu = err_r * t.len2; r.neg_ev = err_r * t.len1; r.lim = err_d * t.len1 * t.len2;
+            r.umin = r.vmin = -__builtin_inff();  // (not read for rays from a point)
+            r.umax = r.vmax = __builtin_inff();
         }
         f32[i] = r;
         return;
@@ -955,6 +957,13 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
         } else {
             q.neg_eu = -eu; q.neg_ev = -ev; q.lim = aa + eu + ev + ea;
         }
+    }
+    {  // extent along the camera's image axes, float64, rounded outward
+        const V3 c = ld3(m.center);
+        const double u0 = dot(p0 - c, axis_u), u1 = dot(p1 - c, axis_u), u2 = dot(p2 - c, axis_u);
+        const double v0 = dot(p0 - c, axis_v), v1 = dot(p1 - c, axis_v), v2 = dot(p2 - c, axis_v);
+        q.umin = -up32(-fmin(u0, fmin(u1, u2))); q.umax = up32(fmax(u0, fmax(u1, u2)));
+        q.vmin = -up32(-fmin(v0, fmin(v1, v2))); q.vmax = up32(fmax(v0, fmax(v1, v2)));
     }
     f32[i] = q;
 }
@@ -1023,6 +1032,19 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
             beam_state[p * kBeamStateDwords + 46] = beam_compact_prefix(beam_cand + p * cands * 3, found & 0xff, kBeamFacesMax, n_kept);
             beam_state[p * kBeamStateDwords + 25] = n_kept;
             beam_suffix_min(beam_cand + p * cands * 3, found & 0xff);
+#ifdef RT_VISIT_STATS
+            if (found & 0xff) {  // leaves listed, faces they hold, faces that survive the bundle's test (per-lane atomics: diagnostics only)
+                int faces_listed = 0, survivors = 0;
+                for (int c = 0; c < (found & 0xff); c++) {
+                    faces_listed += (int)((uint32_t)~beam_cand[(p * cands + c) * 3] & (uint32_t)(kBeamLeafFaces - 1)) + 1;
+                    survivors += __popc((uint32_t)beam_cand[(p * cands + c) * 3 + 2]);
+                }
+                atomicAdd(&g_packet_stats[1], (unsigned long long)(found & 0xff));
+                atomicAdd(&g_packet_stats[11], (unsigned long long)faces_listed);
+                atomicAdd(&g_packet_stats[14], (unsigned long long)survivors);
+                atomicAdd(&g_packet_stats[15], 1ull);
+            }
+#endif
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1972,11 +1994,12 @@ static unsigned persistent_grid(K kernel, size_t lds, int block = kTraceBlock) {
 
 int beam_pixels_max() { return kBeamPixels; }
 
-void launch_beam_prepare(const DScene& sc, int64_t n_faces, bool pyr, const double key[3], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s) {
+void launch_beam_prepare(const DScene& sc, int64_t n_faces, bool pyr, const double key[9], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s) {
     if (n_faces <= 0) return;
     const dim3 grid(blocks_for((size_t)n_faces)), block(kBlock);
-    if (pyr) hipLaunchKernelGGL(k_beam_prepare<true>, grid, block, 0, s, sc, key[0], key[1], key[2], f32, f64, uv);
-    else hipLaunchKernelGGL(k_beam_prepare<false>, grid, block, 0, s, sc, key[0], key[1], key[2], f32, f64, uv);
+    const V3 axis_u = mk(key[3], key[4], key[5]), axis_v = mk(key[6], key[7], key[8]);
+    if (pyr) hipLaunchKernelGGL(k_beam_prepare<true>, grid, block, 0, s, sc, key[0], key[1], key[2], axis_u, axis_v, f32, f64, uv);
+    else hipLaunchKernelGGL(k_beam_prepare<false>, grid, block, 0, s, sc, key[0], key[1], key[2], axis_u, axis_v, f32, f64, uv);
 }
 
 size_t beam_table_bytes(int64_t n_faces, size_t* off_f64, size_t* off_uv) {

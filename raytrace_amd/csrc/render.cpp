@@ -639,7 +639,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
     // Orthographic: the rays share a direction.  Pinhole, or focusable with a lens of radius 0 (camera_focusable.go:26-63: the
     // lens offset is then zero, whatever is drawn): they share their origin, and the image plane must not pass through it.
     bool beam_pyr = false;
-    double beam_key[3] = {cam.dir[0], cam.dir[1], cam.dir[2]};
+    double beam_key[9] = {cam.dir[0], cam.dir[1], cam.dir[2], cam.u[0], cam.u[1], cam.u[2], cam.v[0], cam.v[1], cam.v[2]};
     bool beam_cam = cam.kind == RT_CAM_ORTHOGRAPHIC;
     if (cam.kind == RT_CAM_PINHOLE || (cam.kind == RT_CAM_FOCUSABLE && cam.lens_radius == 0)) {
         const double* org = cam.kind == RT_CAM_PINHOLE ? cam.origin : cam.from;
@@ -651,6 +651,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                               std::sqrt(cam.vertical[0] * cam.vertical[0] + cam.vertical[1] * cam.vertical[1] + cam.vertical[2] * cam.vertical[2]);
         beam_cam = beam_pyr = std::isfinite(away) && std::isfinite(extent) && std::fabs(away) > 1e-9 * extent;
         for (int k = 0; k < 3; k++) beam_key[k] = org[k];
+        for (int k = 3; k < 9; k++) beam_key[k] = 0;
     }
     const bool beam = o->mode == RT_MODE_FAST && sc->mesh_only && sc->all_terminal && rep.dev.n_nodes == 1 && beam_cam && rep.beam_faces > 0 &&
                       o->rays_per_pixel > 1 && !getenv("RT_NO_BEAM");
@@ -923,6 +924,9 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                             "%llu (%.3f %%) have more survivors than the compact array holds and take %.2f %%; per round %.2f leaves looked at, %.2f float32 face tests, %.2f float64\n",
                     ps[0], ps[5], 100.0 * ps[5] / w, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0, ps[6], 100.0 * ps[6] / w, ps[9] ? 100.0 * ps[7] / ps[9] : 0.0,
                     ps[2] / rounds, ps[3] / rounds, ps[4] / rounds);
+        if (getenv("RT_DEBUG_BEAM") && ps[15])
+            fprintf(stderr, "[rt] complete lists %llu: %.2f leaves with %.2f faces each, of which %.2f survive the bundle's test\n", ps[15], (double)ps[1] / ps[15],
+                    (double)ps[11] / ps[15], (double)ps[14] / ps[15]);
         fprintf(stderr, "[rt] wave rounds %llu: %.0f cycles each on average; walks %.0f cycles each (%.0f of them in leaves), %.1f %% of all round cycles\n",
                 ps[10], ps[9] / rounds, ps[8] / w, ps[11] / w, ps[9] ? 100.0 * ps[8] / ps[9] : 0.0);
         unsigned long long ts[64];

@@ -139,8 +139,11 @@ struct BeamFace32 {
     float h[3];  // sign(a) d x e2
     float g[3];  // sign(a) e1 x d
     float neg_eu, neg_ev, lim;
+    // parallel rays only: the face's extent along the camera's two image axes, in the mesh-centred frame (rounded outward).  A
+    // pixel's bundle whose footprint lies beside it cannot hit the face: the axes the three edge tests above leave out.
+    float umin, umax, vmin, vmax;
 };
-static_assert(sizeof(BeamFace32) == 48, "three 16-byte scalar loads");
+static_assert(sizeof(BeamFace32) == 64, "the first three 16-byte pieces are what a ray's pre-test reads");
 
 // The ray-independent half of Face.Collide for one direction.  f is NaN for a face the reference rejects whatever the ray.
 struct BeamFace64 {
