@@ -883,7 +883,7 @@ constexpr int kBeamPixels = RT_BEAM_PIXELS;      // pixels of a work item at mos
 // The lists of a wave's pixels live in LDS, which caps the occupancy: the host sizes them so that the workgroups a CU's registers
 // allow also fit its LDS (launch_beam).
 #ifndef RT_BEAM_CANDS_MAX
-#define RT_BEAM_CANDS_MAX 80
+#define RT_BEAM_CANDS_MAX 96
 #endif
 constexpr int kBeamCandsMax = RT_BEAM_CANDS_MAX;  // (a list's length travels in eight bits)
 constexpr int kBeamStateDwords = 48;
