@@ -968,13 +968,77 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
     f32[i] = q;
 }
 
+// The tree walks of `walk_px` consecutive pixels of tile v (from pixel `first` of the tile on), a lane each: more lanes walk at a
+// time than an item has pixels, and the items of the batch follow one after the other (k_beam).  Every lane leaves its walk's
+// state (what is read of it later: kBeamKeptDwords) and the first instalment of its list in `out`, this wave's stretch of device
+// memory: kBeamWalkPixels states, then as many lists of `cands` triples.  Dynamic LDS, all of which is free at this point: the lanes' stacks
+// (2 * cap dwords each), then their states.
+constexpr int kBeamWalkPixels = 16;
+// What of a walk's state the item's thinning and rounds read (dev_bvh.h): T, the list's length and flags, the bundle's test
+// parameters -- kBeamKeptDwords per pixel, in this order.
+constexpr int kBeamKeptDwords = 16;
+__device__ constexpr int kBeamKeptOrtho[13] = {10, 11, 15, 16, 17, 18, 19, 20, 21, 26, 27, 28, 29};
+__device__ constexpr int kBeamKeptPyr[10] = {10, 11, 15, 19, 20, 21, 22, 23, 24, 45};
+template <bool PYR>
+RT_DEV void beam_walk_batch(const DScene& sc, const DCamera& cam, const PassDesc& pass, long long v, int first, int walk_px, int32_t* __restrict__ out, int p,
+                            int cap, VisitCounts& vc) {
+    const int64_t tile = pass.tile_begin + v;
+    const int64_t group = tile >> 6;
+    const int w = (int)(tile & 63);
+    const int tile_x = ((int)(group % pass.groups_x) * 8 + (w & 7)) * 8;
+    const int tile_y = ((int)(group / pass.groups_x) * 8 + (w >> 3)) * 8;
+    const int cands = pass.beam_cands;
+    const DMesh& m = sc.meshes[sc.nodes[0].index];
+    const FastNode* const tree = sc.fast_nodes + m.beam_off;
+    typedef typename std::conditional<PYR, BeamSlabsPyr, BeamSlabsOrtho>::type Slabs;
+    if (p < walk_px) {
+        int32_t* const st = dyn_lds + walk_px * 2 * cap + p * kBeamStateDwords;
+        int32_t* const list = out + kBeamWalkPixels * kBeamKeptDwords + p * cands * 3;
+        const int pix = first + p;
+        const int lx = tile_x + (pix & 7), ly = tile_y + (pix >> 3);
+        const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);
+        int32_t found = 0;
+        if (lx < pass.dx && ly < pass.local_rows && row < pass.dy) {
+            bool reaches = true;
+            if (PYR) beam_setup_pyr(cam, cam.kind == RT_CAM_PINHOLE ? ld3(cam.origin) : ld3(cam.from), pass.dx, pass.dy, m, lx, pass.dy - 1 - row, st);
+            else reaches = beam_setup(cam, pass.dx, pass.dy, m, lx, pass.dy - 1 - row, st);
+            if (reaches) {
+#ifdef RT_VISIT_STATS
+                uint32_t steps = 0;
+                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, list, cands, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f, steps);
+#else
+                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, list, cands, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f);
+#endif
+                if (st[12] != kFastEmpty) {  // the list goes on: this pixel's rounds walk it in instalments
+                    found |= 0x100;
+                    if (pass.flag) pass.flag[v] = 1u;
+                }
+            }
+        }
+        st[15] = found;
+        if (PYR) {
+#pragma unroll
+            for (int k = 0; k < 10; k++) out[p * kBeamKeptDwords + k] = st[kBeamKeptPyr[k]];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 13; k++) out[p * kBeamKeptDwords + k] = st[kBeamKeptOrtho[k]];
+        }
+    }
+    // what the lanes stored is read by other lanes (beam_item), and the LDS is laid out anew
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One work item: block_px (at most kBeamPixels) consecutive pixels of tile v, all samples of the pass.  Dynamic LDS:
 // the walking lanes' stacks (lane j: 2 * cap dwords at j * 2 * cap), then at pass.beam_offset the lists (kBeamPixels x
 // pass.beam_cands triples), the walks' states, kBeamCullDwords for beam_cull_item32 and the pixels' compact face arrays.
 // PYR: the rays come from one point (pinhole camera; focusable camera without aperture) instead of sharing a direction.
+// The walks of the item's pixels have been done by beam_walk_batch: `walked` is this wave's stretch of device memory with their
+// states and lists, pixel `walked_first` of the batch being the item's first.
 template <bool IMG, bool PYR>
 RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass, const BeamTables& bt, double* __restrict__ film, long long v,
-                      uint32_t sub, int block_px, int p, int cap, uint32_t& n_total, uint32_t& n_left, uint32_t& n_culled, VisitCounts& vc) {
+                      uint32_t sub, int block_px, const int32_t* __restrict__ walked, int walked_first, int p, int cap, uint32_t& n_total, uint32_t& n_left,
+                      uint32_t& n_culled, VisitCounts& vc) {
     const int rounds = (pass.sample_count + 63) >> 6;
     const int64_t tile = pass.tile_begin + v;
     const int64_t group = tile >> 6;
@@ -998,29 +1062,20 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         }
         return beam_setup(cam, pass.dx, pass.dy, m, lx, y, st);
     };
-    // lane j walks the bundle of pixel j of the item: the first instalment of its list, and whether there is more
-    if (p < block_px) {
-        int32_t* const st = beam_state + p * kBeamStateDwords;
-        const int pix = (int)sub * block_px + p;
-        const int lx = tile_x + (pix & 7), ly = tile_y + (pix >> 3);
-        const int row = ((ly >> 4) * pass.band_world + pass.band_rank) * 16 + (ly & 15);
-        int32_t found = 0;
-        if (lx < pass.dx && ly < pass.local_rows && row < pass.dy) {
-#ifdef RT_VISIT_STATS
-            uint32_t steps = 0;
-            if (setup(lx, pass.dy - 1 - row, st)) {
-                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * cands * 3, cands, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f, steps);
-#else
-            if (setup(lx, pass.dy - 1 - row, st)) {
-                found = beam_fill<Slabs>(tree, st, dyn_lds + p * 2 * cap, cap, beam_cand + p * cands * 3, cands, vc.overflow, PYR ? __int_as_float(st[45]) : 1.0f);
-#endif
-                if (st[12] != kFastEmpty) {  // the list goes on: this pixel's rounds walk it in instalments
-                    found |= 0x100;
-                    if (pass.flag) pass.flag[v] = 1u;
-                }
-            }
+    // the pixels' walk states and the first instalments of their lists, from the batch's stretch of device memory
+    {
+        const int32_t* const w_state = walked + walked_first * kBeamKeptDwords;
+        if (p < block_px * kBeamKeptDwords) {  // (kBeamPixels * kBeamKeptDwords = 64: a lane per dword)
+            const int j = p / kBeamKeptDwords, k = p - j * kBeamKeptDwords;
+            if (k < (PYR ? 10 : 13)) beam_state[j * kBeamStateDwords + (PYR ? kBeamKeptPyr[k < 10 ? k : 0] : kBeamKeptOrtho[k < 13 ? k : 0])] = w_state[p];
         }
-        st[15] = found;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int32_t* const w_list = walked + kBeamWalkPixels * kBeamKeptDwords + walked_first * cands * 3;
+        for (int j = 0; j < block_px; j++) {
+            const int n3 = 3 * (__builtin_amdgcn_readfirstlane(beam_state[j * kBeamStateDwords + 15]) & 0xff);
+            for (int k = p; k < n3; k += 64) beam_cand[j * cands * 3 + k] = w_list[j * cands * 3 + k];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1221,7 +1276,6 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     const DCamera& cam = *camp;
     const int p = (int)threadIdx.x;
     const int64_t n_tiles = pass.n_pixels >> 6;
-    const uint32_t n_sub = 64u / (uint32_t)pass.block_px;  // items per tile
     const uint32_t xcd = blockIdx.x & 7;  // workgroup b is dispatched to XCD b % 8
     uint32_t n_total = 0, n_left = 0, n_culled = 0;
     VisitCounts vc{0, 0};
@@ -1229,22 +1283,25 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     const unsigned long long wave_t0 = wall_clock64();
     unsigned long long wave_items = 0;
 #endif
-    // Draws the next item of one queue: tile number (or -1 when that queue is exhausted), sub-block and pixels of the item.
-    // The first queue_flagged[owner] tiles of a scheduled queue hold pixels that take milliseconds each (refine_tile_order):
-    // they are handed out a pixel at a time, so that no wave gets several of those in one item.
-    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out, uint32_t& px_out) {
+    // Draws the next batch of one queue: tile number (or -1 when that queue is exhausted), which batch of the tile, and the
+    // pixels of a batch and of an item.  The first queue_flagged[owner] tiles of a scheduled queue hold pixels that take
+    // milliseconds each (refine_tile_order): they are handed out a pixel at a time, so that no wave gets several of those.
+    const uint32_t walk_px = (uint32_t)pass.walk_px, n_batches = 64u / walk_px;  // batches per tile
+    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out, uint32_t& px_out, uint32_t& walk_out) {
         const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
-        const uint32_t fine = pass.order ? pass.queue_flagged[owner] * 64u : 0u;  // items of one pixel at the front of the queue
+        const uint32_t fine = pass.order ? pass.queue_flagged[owner] * 64u : 0u;  // batches of one pixel at the front of the queue
         uint32_t idx;
         if (item < fine) {
             idx = item >> 6;
             sub_out = item & 63u;
             px_out = 1u;
+            walk_out = 1u;
         } else {
             const uint32_t rest = item - fine;
-            idx = (fine >> 6) + rest / n_sub;
-            sub_out = rest - (rest / n_sub) * n_sub;
+            idx = (fine >> 6) + rest / n_batches;
+            sub_out = rest - (rest / n_batches) * n_batches;
             px_out = (uint32_t)pass.block_px;
+            walk_out = walk_px;
         }
         long long cand = -1;
         if (pass.order) {
@@ -1254,21 +1311,23 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         }
         tile_out = (cand >= 0 && cand < n_tiles) ? cand : -1;
     };
-    // the item after the current one is drawn while the current one is traced (the atomic's round trip is off the critical path)
+    int32_t* const walked = bt.walk_scratch + (size_t)blockIdx.x * (size_t)bt.walk_stride;
+    // the batch after the current one is drawn while the current one is traced (the atomic's round trip is off the critical path)
     long long ahead_v = -1;
-    uint32_t ahead_sub = 0, ahead_px = 1;
-    if (p == 0) draw(xcd, ahead_v, ahead_sub, ahead_px);
+    uint32_t ahead_sub = 0, ahead_px = 1, ahead_walk = 1;
+    if (p == 0) draw(xcd, ahead_v, ahead_sub, ahead_px, ahead_walk);
     for (;;) {
         long long v = -1;
-        uint32_t sub = 0, px = 1;
+        uint32_t sub = 0, px = 1, wpx = 1;
         if (p == 0) {
             if (ahead_v >= 0) {
                 v = ahead_v;
                 sub = ahead_sub;
                 px = ahead_px;
-                draw(xcd, ahead_v, ahead_sub, ahead_px);
+                wpx = ahead_walk;
+                draw(xcd, ahead_v, ahead_sub, ahead_px, ahead_walk);
             } else {  // own queue exhausted (cursors only grow): take from the other XCDs' queues
-                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub, px);
+                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub, px, wpx);
             }
         }
         // lane 0's values, as scalars: everything derived from them (the item's pixels) stays in scalar registers
@@ -1277,8 +1336,11 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         if (v < 0) break;
         sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
         px = (uint32_t)__builtin_amdgcn_readfirstlane((int)px);
+        wpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wpx);
         const long long t_start = pass.cost ? clock64() : 0;
-        beam_item<IMG, PYR>(sc, cam, pass, bt, film, v, sub, (int)px, p, sc.stack_pairs, n_total, n_left, n_culled, vc);
+        beam_walk_batch<PYR>(sc, cam, pass, v, (int)(sub * wpx), (int)wpx, walked, p, sc.stack_pairs, vc);
+        for (uint32_t part = 0; part * px < wpx; part++)
+            beam_item<IMG, PYR>(sc, cam, pass, bt, film, v, sub * (wpx / px) + part, (int)px, walked, (int)(part * px), p, sc.stack_pairs, n_total, n_left, n_culled, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
 #ifdef RT_WAVE_TIMES
         wave_items++;
@@ -2002,6 +2064,9 @@ void launch_beam_prepare(const DScene& sc, int64_t n_faces, bool pyr, const doub
     else hipLaunchKernelGGL(k_beam_prepare<false>, grid, block, 0, s, sc, key[0], key[1], key[2], axis_u, axis_v, f32, f64, uv);
 }
 
+int beam_walk_stride() { return kBeamWalkPixels * (kBeamKeptDwords + kBeamCandsMax * 3); }
+static_assert(kBeamPixels * kBeamKeptDwords <= 64, "beam_item fetches the kept states with a lane per dword");
+
 size_t beam_table_bytes(int64_t n_faces, size_t* off_f64, size_t* off_uv) {
     const size_t n = (size_t)n_faces, a = (n * sizeof(BeamFace32) + 255) & ~(size_t)255, b = (n * sizeof(BeamFace64) + 255) & ~(size_t)255;
     if (off_f64) *off_f64 = a;
@@ -2032,10 +2097,20 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     if (share > lds + fixed + 16 * per_leaf) cands = (int)std::min<size_t>(kBeamCandsMax, (share - lds - fixed) / per_leaf);
     pd.beam_cands = cands;
     lds += fixed + (size_t)cands * per_leaf;
+    // Pixels walked together: as many lanes as the LDS has room for their stacks and states (before the lists are needed),
+    // for a frame or a large share of one; an item's own for a small share, whose launch wants many small pieces of work.
+    // Measured with 4 / 8 / 16 pixels per walk, ms per launch: the 4K scan frame 69.0 / 64.4 / 62.1, a quarter of it - / 16.6 / 16.4, an
+    // eighth 9.2 / 8.75 / 9.2; the same scene at 1920x1080 21.1 / 20.1 / 20.3, a quarter of that 5.7 / 5.7 / 6.7, an eighth 4.7 / 4.8 / 5.8.
+    int walk_px = pass.block_px;
+    int want_walk = pass.n_pixels >= 2000000 ? 16 : (pass.n_pixels >= 700000 ? 8 : pass.block_px);
+    if (const char* e = getenv("RT_BEAM_WALK_PX")) want_walk = atoi(e);  // tuning knob
+    while (walk_px * 2 <= want_walk && walk_px * 2 <= 16 && (size_t)(walk_px * 2) * (2 * (size_t)sc.stack_pairs + kBeamStateDwords) * sizeof(int32_t) <= lds) walk_px *= 2;
+    pd.walk_px = walk_px;
+    if (!bt.walk_scratch || bt.walk_stride < beam_walk_stride()) return false;
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);
-        const unsigned waves = std::min(resident, (tiles + 7u) & ~7u);
+        const unsigned waves = std::min(std::min(resident, (tiles + 7u) & ~7u), (unsigned)kBeamWalkWaves);  // (a stretch of walk_scratch each)
         hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), lds, s, sc, cam, pd, counters, bt, film);
     };
     if (bt.pyramid) { if (bt.image) go(k_beam<true, true, RT_BEAM_WAVES>); else go(k_beam<false, true, RT_BEAM_WAVES>); }

@@ -162,8 +162,10 @@ struct BeamTables {
     int32_t safe_camera;  // 1: every origin the camera can produce is finite (the host has looked at its constants): the NaN / Inf guard of render.go:147-150 cannot fire
     int32_t image;        // 1: the material is an Emitter whose texture is a TextureImage (the kernel samples it in line)
     int32_t pyramid;      // 0: the tables are for a direction (orthographic camera); 1: for a point every ray starts from (pinhole camera, focusable camera without aperture)
-    int32_t pad;
+    int32_t walk_stride;     // dwords of a wave's stretch of walk_scratch
+    int32_t* walk_scratch;   // kBeamWalkWaves stretches, one per persistent wave of k_beam: the states and lists of the pixels whose trees it has just walked (kernels.hip, beam_walk_batch)
 };
+constexpr int kBeamWalkWaves = 8192;
 
 struct DCamera {
     int32_t kind, pad;
