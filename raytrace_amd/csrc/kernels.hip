@@ -971,9 +971,9 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
 // The tree walks of `walk_px` consecutive pixels of tile v (from pixel `first` of the tile on), a lane each: more lanes walk at a
 // time than an item has pixels, and the items of the batch follow one after the other (k_beam).  Every lane leaves its walk's
 // state (what is read of it later: kBeamKeptDwords) and the first instalment of its list in `out`, this wave's stretch of device
-// memory: kBeamWalkPixels states, then as many lists of `cands` triples.  Dynamic LDS, all of which is free at this point: the lanes' stacks
-// (2 * cap dwords each), then their states.
-constexpr int kBeamWalkPixels = 16;
+// memory: kBeamWalkPixels states, then as many lists of `cands` triples.  Dynamic LDS, all of which is free at this point: the
+// lanes' stacks (2 * cap dwords each); a walking lane's state is private to it.
+constexpr int kBeamWalkPixels = 16;  // (32 measured the same as 16 on the 4K scan)
 // What of a walk's state the item's thinning and rounds read (dev_bvh.h): T, the list's length and flags, the bundle's test
 // parameters -- kBeamKeptDwords per pixel, in this order.
 constexpr int kBeamKeptDwords = 16;
@@ -992,7 +992,7 @@ RT_DEV void beam_walk_batch(const DScene& sc, const DCamera& cam, const PassDesc
     const FastNode* const tree = sc.fast_nodes + m.beam_off;
     typedef typename std::conditional<PYR, BeamSlabsPyr, BeamSlabsOrtho>::type Slabs;
     if (p < walk_px) {
-        int32_t* const st = dyn_lds + walk_px * 2 * cap + p * kBeamStateDwords;
+        int32_t st[kBeamStateDwords];
         int32_t* const list = out + kBeamWalkPixels * kBeamKeptDwords + p * cands * 3;
         const int pix = first + p;
         const int lx = tile_x + (pix & 7), ly = tile_y + (pix >> 3);
@@ -2097,14 +2097,15 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     if (share > lds + fixed + 16 * per_leaf) cands = (int)std::min<size_t>(kBeamCandsMax, (share - lds - fixed) / per_leaf);
     pd.beam_cands = cands;
     lds += fixed + (size_t)cands * per_leaf;
-    // Pixels walked together: as many lanes as the LDS has room for their stacks and states (before the lists are needed),
+    // Pixels walked together: as many lanes as the LDS has room for their stacks (before the lists are needed),
     // for a frame or a large share of one; an item's own for a small share, whose launch wants many small pieces of work.
     // Measured with 4 / 8 / 16 pixels per walk, ms per launch: the 4K scan frame 69.0 / 64.4 / 62.1, a quarter of it - / 16.6 / 16.4, an
     // eighth 9.2 / 8.75 / 9.2; the same scene at 1920x1080 21.1 / 20.1 / 20.3, a quarter of that 5.7 / 5.7 / 6.7, an eighth 4.7 / 4.8 / 5.8.
     int walk_px = pass.block_px;
     int want_walk = pass.n_pixels >= 2000000 ? 16 : (pass.n_pixels >= 700000 ? 8 : pass.block_px);
     if (const char* e = getenv("RT_BEAM_WALK_PX")) want_walk = atoi(e);  // tuning knob
-    while (walk_px * 2 <= want_walk && walk_px * 2 <= 16 && (size_t)(walk_px * 2) * (2 * (size_t)sc.stack_pairs + kBeamStateDwords) * sizeof(int32_t) <= lds) walk_px *= 2;
+    const size_t walk_lane = 2 * (size_t)sc.stack_pairs * sizeof(int32_t);  // a walking lane's stack
+    while (walk_px * 2 <= want_walk && walk_px * 2 <= kBeamWalkPixels && (size_t)(walk_px * 2) * walk_lane <= lds) walk_px *= 2;
     pd.walk_px = walk_px;
     if (!bt.walk_scratch || bt.walk_stride < beam_walk_stride()) return false;
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
