@@ -21,6 +21,7 @@ struct PassDesc {
     int32_t acc_offset;             // primary launch: where the pixels' running sums start in dynamic LDS, in dwords (set by launch_primary)
     int32_t beam_offset;            // ... and where the pixel beams' lists and walk states start (set by launch_beam)
     int32_t beam_cands;             // pixel beams: leaves a pixel's list holds at a time (set by launch_beam)
+    uint32_t beam_serial;           // pixel beams: number of the launch (set by launch_beam): marks the entries of BeamTables::long_px that belong to it; 0: that queue is not used
     int32_t walk_px;                // pixel beams: pixels whose trees are walked together, a lane each: block_px times a power of two, at most 16 (set by launch_beam)
     int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group
     int64_t n_pixels;               // tiles * 64 = pixels (threads) of this pass
@@ -33,9 +34,7 @@ struct PassDesc {
     int32_t cull_pixels;            // pixel beams: a pixel whose bundle of rays misses the mesh is settled without generating its rays (they are counted)
     const int32_t* order;
     uint32_t* cost;
-    uint32_t* flag;                 // pixel beams: set, flag[tile] becomes 1 when a pixel of the tile lists more leaves than one instalment holds (its rounds run many times longer than others': the host then schedules such tiles first)
     uint32_t queue_off[8], queue_len[8];
-    uint32_t queue_flagged[8];      // pixel beams: that many tiles at the front of each scheduled queue are handed out a pixel at a time (render.cpp, refine_tile_order)
 };
 
 struct Queues {

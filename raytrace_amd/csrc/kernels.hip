@@ -12,6 +12,7 @@
 //   k_resolve   film sums -> 8-bit RGBA exactly as renderPixel quantises (render.go:218-224)
 #include "kernels.h"
 
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -972,7 +973,8 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
 // time than an item has pixels, and the items of the batch follow one after the other (k_beam).  Every lane leaves its walk's
 // state (what is read of it later: kBeamKeptDwords) and the first instalment of its list in `out`, this wave's stretch of device
 // memory: kBeamWalkPixels states, then as many lists of `cands` triples.  Dynamic LDS, all of which is free at this point: the
-// lanes' stacks (2 * cap dwords each); a walking lane's state is private to it.
+// lanes' stacks (2 * cap dwords each); a walking lane's state is private to it.  `defer`: a pixel whose list goes on beyond its
+// first instalment is put into the launch's queue of such pixels (long_px, counters->long_px) instead; true: at least one was.
 constexpr int kBeamWalkPixels = 16;  // (32 measured the same as 16 on the 4K scan)
 // What of a walk's state the item's thinning and rounds read (dev_bvh.h): T, the list's length and flags, the bundle's test
 // parameters -- kBeamKeptDwords per pixel, in this order.
@@ -980,8 +982,8 @@ constexpr int kBeamKeptDwords = 16;
 __device__ constexpr int kBeamKeptOrtho[13] = {10, 11, 15, 16, 17, 18, 19, 20, 21, 26, 27, 28, 29};
 __device__ constexpr int kBeamKeptPyr[10] = {10, 11, 15, 19, 20, 21, 22, 23, 24, 45};
 template <bool PYR>
-RT_DEV void beam_walk_batch(const DScene& sc, const DCamera& cam, const PassDesc& pass, long long v, int first, int walk_px, int32_t* __restrict__ out, int p,
-                            int cap, VisitCounts& vc) {
+RT_DEV bool beam_walk_batch(const DScene& sc, const DCamera& cam, const PassDesc& pass, long long v, int first, int walk_px, int32_t* __restrict__ out, int p,
+                            int cap, bool defer, Counters* __restrict__ counters, unsigned long long* __restrict__ long_px, VisitCounts& vc) {
     const int64_t tile = pass.tile_begin + v;
     const int64_t group = tile >> 6;
     const int w = (int)(tile & 63);
@@ -991,6 +993,7 @@ RT_DEV void beam_walk_batch(const DScene& sc, const DCamera& cam, const PassDesc
     const DMesh& m = sc.meshes[sc.nodes[0].index];
     const FastNode* const tree = sc.fast_nodes + m.beam_off;
     typedef typename std::conditional<PYR, BeamSlabsPyr, BeamSlabsOrtho>::type Slabs;
+    bool handed_on = false;
     if (p < walk_px) {
         int32_t st[kBeamStateDwords];
         int32_t* const list = out + kBeamWalkPixels * kBeamKeptDwords + p * cands * 3;
@@ -1011,7 +1014,14 @@ RT_DEV void beam_walk_batch(const DScene& sc, const DCamera& cam, const PassDesc
 #endif
                 if (st[12] != kFastEmpty) {  // the list goes on: this pixel's rounds walk it in instalments
                     found |= 0x100;
-                    if (pass.flag) pass.flag[v] = 1u;
+                    if (defer) {  // such a pixel takes milliseconds: not one of several of an item, but an item of its own for the wave that draws next (k_beam)
+                        const uint32_t slot = (uint32_t)(atomicAdd(&counters->long_px.head_tail, 1ull << 32) >> 32);
+                        if (slot < kBeamLongCap) {
+                            atomicExch(&long_px[slot], ((unsigned long long)pass.beam_serial << 32) | (unsigned long long)(uint32_t)(v * 64 + pix));
+                            found = 0x200;  // nothing listed, and beam_item leaves the pixel alone
+                            handed_on = true;
+                        }
+                    }
                 }
             }
         }
@@ -1027,6 +1037,7 @@ RT_DEV void beam_walk_batch(const DScene& sc, const DCamera& cam, const PassDesc
     // what the lanes stored is read by other lanes (beam_item), and the LDS is laid out anew
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    return __ballot(handed_on) != 0;
 }
 
 // One work item: block_px (at most kBeamPixels) consecutive pixels of tile v, all samples of the pass.  Dynamic LDS:
@@ -1130,6 +1141,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         int32_t* const px_state = beam_state + pb * kBeamStateDwords;
         int32_t* const px_cand = beam_cand + pb * cands * 3;
         const int32_t found = __builtin_amdgcn_readfirstlane(px_state[15]);
+        if (found & 0x200) continue;  // handed on by beam_walk_batch: an item of its own
         const int beam_first = found & 0xff;
 #if defined(RT_KO_LONG_CODE)  // knock-out builds (wrong pictures): the pixels with long lists skipped, and the code of their rounds left out as well
         if (found & 0x100) continue;
@@ -1283,26 +1295,12 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     const unsigned long long wave_t0 = wall_clock64();
     unsigned long long wave_items = 0;
 #endif
-    // Draws the next batch of one queue: tile number (or -1 when that queue is exhausted), which batch of the tile, and the
-    // pixels of a batch and of an item.  The first queue_flagged[owner] tiles of a scheduled queue hold pixels that take
-    // milliseconds each (refine_tile_order): they are handed out a pixel at a time, so that no wave gets several of those.
+    // Draws the next batch of one queue: tile number (or -1 when that queue is exhausted) and which batch of the tile.
     const uint32_t walk_px = (uint32_t)pass.walk_px, n_batches = 64u / walk_px;  // batches per tile
-    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out, uint32_t& px_out, uint32_t& walk_out) {
+    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
         const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
-        const uint32_t fine = pass.order ? pass.queue_flagged[owner] * 64u : 0u;  // batches of one pixel at the front of the queue
-        uint32_t idx;
-        if (item < fine) {
-            idx = item >> 6;
-            sub_out = item & 63u;
-            px_out = 1u;
-            walk_out = 1u;
-        } else {
-            const uint32_t rest = item - fine;
-            idx = (fine >> 6) + rest / n_batches;
-            sub_out = rest - (rest / n_batches) * n_batches;
-            px_out = (uint32_t)pass.block_px;
-            walk_out = walk_px;
-        }
+        const uint32_t idx = item / n_batches;
+        sub_out = item - idx * n_batches;
         long long cand = -1;
         if (pass.order) {
             if (idx < pass.queue_len[owner]) cand = pass.order[pass.queue_off[owner] + idx];
@@ -1311,23 +1309,96 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         }
         tile_out = (cand >= 0 && cand < n_tiles) ? cand : -1;
     };
+    // The pixels that take milliseconds each (their list of leaves goes on beyond one instalment, and every round walks the tree
+    // again) are not traced by the wave that meets them in a batch: it puts them into a queue of the launch, and a wave that is
+    // about to draw takes one of those first, as an item of one pixel -- so no wave gets several of them, wherever they lie in the
+    // tile queues.  An entry carries the launch's number: the slot may have been reserved and not yet written.  Takes the
+    // oldest entry (false: none); `ht`: the cursors as the caller has read them (glance: a load, which may be a little old;
+    // look: a read-modify-write, which is performed at the memory side whatever the caches hold).
+    auto glance = [&]() { return __hip_atomic_load(&counters->long_px.head_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto look_up = [&]() { return atomicAdd(&counters->long_px.head_tail, 0ull); };
+    auto draw_long = [&](long long& tile_out, uint32_t& sub_out, unsigned long long ht) -> bool {
+        uint32_t slot;
+        for (;;) {
+            slot = (uint32_t)ht;
+            const uint32_t reserved = (uint32_t)(ht >> 32);
+            if (slot >= (reserved < kBeamLongCap ? reserved : kBeamLongCap)) return false;
+            const unsigned long long seen = atomicCAS(&counters->long_px.head_tail, ht, ht + 1);  // (fails whenever another wave took or added one: so many retries at most)
+            if (seen == ht) break;
+            ht = seen;
+        }
+        unsigned long long e = 0;
+        for (int spin = 0; spin < (1 << 22); spin++) {  // the wave that reserved the slot writes it within a few instructions
+            e = atomicOr(&bt.long_px[slot], 0ull);
+            if ((uint32_t)(e >> 32) == pass.beam_serial) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if ((uint32_t)(e >> 32) != pass.beam_serial) {  // (never seen; reported like a stack that ran full rather than left to hang)
+            vc.overflow = 1;
+            return false;
+        }
+        tile_out = (long long)((uint32_t)e >> 6);
+        sub_out = (uint32_t)e & 63u;
+        return true;
+    };
+    const bool may_defer = walk_px > 1 && pass.beam_serial != 0 && n_tiles <= (1ll << 25);  // (an entry holds tile * 64 + pixel in 32 bits)
     int32_t* const walked = bt.walk_scratch + (size_t)blockIdx.x * (size_t)bt.walk_stride;
     // the batch after the current one is drawn while the current one is traced (the atomic's round trip is off the critical path)
     long long ahead_v = -1;
-    uint32_t ahead_sub = 0, ahead_px = 1, ahead_walk = 1;
-    if (p == 0) draw(xcd, ahead_v, ahead_sub, ahead_px, ahead_walk);
+    uint32_t ahead_sub = 0;
+    unsigned long long ahead_ht = 0;  // the long pixels' cursors, read when the batch ahead was drawn
+    bool pusher = may_defer;  // (lane 0's) this wave may still add to the queue of long pixels: it has not found the tile queues empty
+    bool pushed = false;      // ... and has added to it
+    if (p == 0) draw(xcd, ahead_v, ahead_sub);
     for (;;) {
         long long v = -1;
         uint32_t sub = 0, px = 1, wpx = 1;
         if (p == 0) {
-            if (ahead_v >= 0) {
+            bool tiles_left = true;
+            if (may_defer && draw_long(v, sub, ahead_ht)) {
+                // (px = wpx = 1)
+            } else if (ahead_v >= 0) {
                 v = ahead_v;
                 sub = ahead_sub;
-                px = ahead_px;
-                wpx = ahead_walk;
-                draw(xcd, ahead_v, ahead_sub, ahead_px, ahead_walk);
+                px = (uint32_t)pass.block_px;
+                wpx = walk_px;
+                draw(xcd, ahead_v, ahead_sub);
+                if (may_defer) ahead_ht = glance();
             } else {  // own queue exhausted (cursors only grow): take from the other XCDs' queues
-                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub, px, wpx);
+                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub);
+                if (may_defer) ahead_ht = glance();
+                px = (uint32_t)pass.block_px;
+                wpx = walk_px;
+                tiles_left = v >= 0;
+            }
+            if (!tiles_left && may_defer) {
+                // No batches left.  What this wave has put into the queue of long pixels is there (the fence), and whatever any wave
+                // still puts there that wave will find when it comes here, so a wave that finds the queue empty may go.  But the
+                // last batches' long pixels are better shared: some of the waves (512: more would only crowd the memory channel
+                // of the cursors) stay until no wave can add any more, looking every few microseconds, a hundred thousand times at most.
+                if (pusher) {
+                    __threadfence();
+                    atomicAdd(&counters->long_done[xcd].v, 1u);
+                    pusher = false;
+                }
+                const bool stays = blockIdx.x < 512;
+                auto all_done = [&](bool surely) {
+                    uint32_t n = 0;
+                    for (int k = 0; k < 8; k++)
+                        n += surely ? atomicAdd(&counters->long_done[k].v, 0u) : __hip_atomic_load(&counters->long_done[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return n >= gridDim.x;
+                };
+                for (int look = 0; look < 100000; look++) {
+                    // (a wave that has added nothing may go on a glance; one that has must see its own additions)
+                    if (draw_long(v, sub, (look == 0 && pushed) ? look_up() : glance()) || !stays) break;
+                    if (all_done(false) && all_done(true)) {
+                        __threadfence();
+                        (void)draw_long(v, sub, look_up());
+                        break;
+                    }
+                    for (int nap = 0; nap < 4; nap++) __builtin_amdgcn_s_sleep(127);
+                }
+                px = wpx = 1;
             }
         }
         // lane 0's values, as scalars: everything derived from them (the item's pixels) stays in scalar registers
@@ -1338,7 +1409,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         px = (uint32_t)__builtin_amdgcn_readfirstlane((int)px);
         wpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wpx);
         const long long t_start = pass.cost ? clock64() : 0;
-        beam_walk_batch<PYR>(sc, cam, pass, v, (int)(sub * wpx), (int)wpx, walked, p, sc.stack_pairs, vc);
+        if (beam_walk_batch<PYR>(sc, cam, pass, v, (int)(sub * wpx), (int)wpx, walked, p, sc.stack_pairs, may_defer && wpx > 1, counters, bt.long_px, vc)) pushed = true;
         for (uint32_t part = 0; part * px < wpx; part++)
             beam_item<IMG, PYR>(sc, cam, pass, bt, film, v, sub * (wpx / px) + part, (int)px, walked, (int)(part * px), p, sc.stack_pairs, n_total, n_left, n_culled, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
@@ -2107,7 +2178,10 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     const size_t walk_lane = 2 * (size_t)sc.stack_pairs * sizeof(int32_t);  // a walking lane's stack
     while (walk_px * 2 <= want_walk && walk_px * 2 <= kBeamWalkPixels && (size_t)(walk_px * 2) * walk_lane <= lds) walk_px *= 2;
     pd.walk_px = walk_px;
-    if (!bt.walk_scratch || bt.walk_stride < beam_walk_stride()) return false;
+    if (!bt.walk_scratch || bt.walk_stride < beam_walk_stride() || !bt.long_px) return false;
+    static std::atomic<uint32_t> serial{0};
+    do pd.beam_serial = ++serial; while (pd.beam_serial == 0);
+    if (getenv("RT_NO_LONG_QUEUE")) pd.beam_serial = 0;  // test knob: every wave traces the pixels with long lists that it meets
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);

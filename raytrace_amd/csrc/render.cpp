@@ -53,9 +53,7 @@ struct WorkBuffers {
     size_t order_tiles = 0;
     std::string order_key;
     bool order_valid = false;
-    uint32_t queue_off[8] = {}, queue_len[8] = {}, queue_flagged[8] = {};
-    std::vector<int32_t> host_order;  // the schedule as uploaded
-    bool order_refined = false;       // the first pixel-beam launch that ran from it has told which tiles hold pixels with long lists, and they have moved to the front
+    uint32_t queue_off[8] = {}, queue_len[8] = {};
     uint64_t culled_pixels = 0;  // pixels of the tiles the schedule leaves out (outside the screen bounds of the scene)
     bool is_static = false;      // the buffers live in the library's static scratch: nothing to allocate, grow or free
 };
@@ -193,10 +191,8 @@ int ensure_work(const rt_scene* sc, Replica& rep, uint64_t want_paths) {
         std::swap(w->order_tiles, old->order_tiles);
         std::swap(w->order_key, old->order_key);
         std::swap(w->order_valid, old->order_valid);
-        std::swap(w->host_order, old->host_order);
-        std::swap(w->order_refined, old->order_refined);
         std::swap(w->culled_pixels, old->culled_pixels);
-        for (int k = 0; k < 8; k++) { std::swap(w->queue_off[k], old->queue_off[k]); std::swap(w->queue_len[k], old->queue_len[k]); std::swap(w->queue_flagged[k], old->queue_flagged[k]); }
+        for (int k = 0; k < 8; k++) { std::swap(w->queue_off[k], old->queue_off[k]); std::swap(w->queue_len[k], old->queue_len[k]); }
         destroy_work(old);
     }
     rep.work = w;
@@ -425,33 +421,6 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& ge
     }
     HIP_TRY(hipMemcpyAsync(w.tile_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));  // `order` goes out of scope
-    w.host_order = std::move(order);
-    w.order_refined = false;
-    for (int k = 0; k < 8; k++) w.queue_flagged[k] = 0;
-    return RT_OK;
-}
-
-// After the first pixel-beam launch that ran from the schedule: the tiles it flagged (a pixel whose bundle of rays grazes the
-// mesh lists more leaves than one instalment holds, and each of its rounds then walks the tree again: milliseconds for one
-// pixel) move to the front of their queues, so that no wave starts on one of them when the others are about to finish.
-// Measured on the 4K scan: the last wave of a launch ended 2.1 ms after the 99th percentile (78.4 against 76.3 ms).
-int refine_tile_order(WorkBuffers& w, int64_t tiles_total, hipStream_t stream) {
-    std::vector<uint32_t> flag((size_t)tiles_total);
-    HIP_TRY(hipMemcpyAsync(flag.data(), w.tile_cost, flag.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (int k = 0; k < 8; k++) {
-        const auto first = w.host_order.begin() + w.queue_off[k];
-        const auto mid = std::stable_partition(first, first + w.queue_len[k], [&](int32_t t) { return flag[(size_t)t] != 0; });
-        w.queue_flagged[k] = (uint32_t)(mid - first);
-    }
-    HIP_TRY(hipMemcpyAsync(w.tile_order, w.host_order.data(), w.host_order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    w.order_refined = true;
-    if (std::getenv("RT_DEBUG")) {
-        uint32_t n = 0;
-        for (int k = 0; k < 8; k++) n += w.queue_flagged[k];
-        fprintf(stderr, "[rt] tile schedule refined: %u tiles hold pixels with long lists\n", n);
-    }
     return RT_OK;
 }
 
@@ -711,7 +680,6 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
         }
         if (pilot) s_count = std::min(s_count, kPilotSamples);
         else plan(s_count);
-        bool learned = false;  // a launch of this pass wrote tile flags (pixel beams)
         for (int64_t t0 = 0; t0 < tiles_total; t0 += tiles_per_launch) {
             if (sc->cancel.load()) {
                 (void)hipStreamSynchronize(stream);
@@ -728,8 +696,8 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 if (beam && !item_rays_fixed) {
                     // Pixel beams: a lane walks the tree for each pixel of an item, so more pixels keep more lanes busy in that
                     // phase (kBeamPixels at most); against that, the fewer items a resident wave gets the longer the chip waits for
-                    // the last ones.  (The pixels that take milliseconds each are handed out one at a time whatever this says, once
-                    // the schedule knows them: refine_tile_order.)  Measured with k_beam at 1024 samples, ms per launch with items of
+                    // the last ones.  (The pixels that take milliseconds each become items of their own whatever this says: k_beam's
+                    // queue of long pixels.)  Measured with k_beam at 1024 samples, ms per launch with items of
                     // 1 / 2 / 4 pixels: the 4K scan frame 97.2 / 81.2 / 73.3, a quarter of it 24.7 / 20.6 / 18.8, an eighth 12.8 / 10.7 / 9.7;
                     // the same scene at 1920x1080 29.3 / 25.5 / 23.8, a quarter of that 7.7 / 6.8 / 6.8, an eighth 5.6 / 5.1 / 5.8.
                     const int64_t share_px = tiles_total * 64;
@@ -750,15 +718,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
             const bool whole = t0 == 0 && nt == tiles_total;
             pass.order = (want_order && w.order_valid && whole) ? w.tile_order : nullptr;
             pass.cost = (pilot && whole) ? w.tile_cost : nullptr;
-            // (a launch of under 134 M rays -- a millisecond -- is over before the flags could repay their trip to the host and back)
-            const bool learn = beam && pass.order && !pass.cost && !w.order_refined && !w.host_order.empty() && nt * 64 * (int64_t)s_count >= ((int64_t)1 << 27) &&
-                               !getenv("RT_NO_ORDER_REFINE");
-            pass.flag = learn ? w.tile_cost : nullptr;
-            if (learn) {
-                HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
-                learned = true;
-            }
-            for (int k = 0; k < 8; k++) { pass.queue_off[k] = w.queue_off[k]; pass.queue_len[k] = w.queue_len[k]; pass.queue_flagged[k] = w.order_refined ? w.queue_flagged[k] : 0; }
+            for (int k = 0; k < 8; k++) { pass.queue_off[k] = w.queue_off[k]; pass.queue_len[k] = w.queue_len[k]; }
             if (pass.cost) HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
             if (int rc = reset_cursors()) return rc;
             EventPair* ev = nullptr;
@@ -865,8 +825,6 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 cur = 1 - cur;
             }
         }
-        if (learned)
-            if (int rc = refine_tile_order(w, tiles_total, stream)) return rc;
         if (pilot) {
             Occupancy occ;
             TileGeometry geo{o->dx, o->dy, pass.groups_x, pass.local_rows, pass.band_rank, pass.band_world, nullptr};

@@ -654,6 +654,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             // a stretch per persistent wave for the walks of 16 pixels: their states and lists of up to kBeamCandsMax leaves (154 MB)
             rep->beam.walk_stride = beam_walk_stride();
             HIP_TRY(rep->mem.alloc((size_t)kBeamWalkWaves * (size_t)rep->beam.walk_stride, &rep->beam.walk_scratch));
+            HIP_TRY(rep->mem.alloc((size_t)kBeamLongCap, &rep->beam.long_px));
+            HIP_TRY(hipMemset(rep->beam.long_px, 0, (size_t)kBeamLongCap * sizeof(unsigned long long)));  // (no launch has the number 0)
         }
         HIP_TRY(hipEventCreateWithFlags(&rep->done, hipEventDisableTiming));
         if (r > 0) HIP_TRY(hipStreamCreateWithFlags(&rep->stream, hipStreamNonBlocking));

@@ -164,8 +164,10 @@ struct BeamTables {
     int32_t pyramid;      // 0: the tables are for a direction (orthographic camera); 1: for a point every ray starts from (pinhole camera, focusable camera without aperture)
     int32_t walk_stride;     // dwords of a wave's stretch of walk_scratch
     int32_t* walk_scratch;   // kBeamWalkWaves stretches, one per persistent wave of k_beam: the states and lists of the pixels whose trees it has just walked (kernels.hip, beam_walk_batch)
+    unsigned long long* long_px;  // kBeamLongCap entries: the pixels of a launch whose rounds walk the tree again (milliseconds each), handed from the wave that met them to whichever wave draws next (kernels.hip, k_beam)
 };
 constexpr int kBeamWalkWaves = 8192;
+constexpr uint32_t kBeamLongCap = 1u << 20;  // (a wave that finds the queue full traces the pixel itself)
 
 struct DCamera {
     int32_t kind, pad;
@@ -248,6 +250,10 @@ struct Counters {
     Cursor tile_cursor[8];                     // next tile of each XCD's share of a primary launch
     Cursor in_cursor[kRayStripes];             // k_walk: next unclaimed ray of each stripe of the generation being traced
     Cursor hit_cursor[kQueueStripes];          // k_walk: append cursors of the hit records, one per stripe
+    struct alignas(128) LongPixels {           // k_beam: the queue BeamTables::long_px
+        unsigned long long head_tail;          // entries taken (low half) and entries reserved (high half): one load reads both
+    } long_px;
+    Cursor long_done[8];                       // k_beam: waves of each XCD that have found the tile queues empty, and so add nothing more to that queue
 };
 
 }  // namespace rt

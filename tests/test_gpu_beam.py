@@ -94,11 +94,12 @@ def test_long_lists_and_odd_views(ob, monkeypatch, view):
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, view
 
 
-def test_tiles_with_long_lists_first_and_a_pixel_at_a_time(monkeypatch):
-    """A sheet seen along its plane at 512 x 512 x 512 samples: many pixels list more leaves than a list holds, and the launch
-    is large enough (2^27 rays) for the library to learn which tiles hold them and to schedule those first, a pixel per work
-    item.  Frames rendered from the refined schedule, from the plain one (RT_NO_ORDER_REFINE=1) and by the packet walk must
-    be the same film, number for number: a pixel's sum is one wave's, added in one order, however the items are cut."""
+def test_pixels_with_long_lists_change_hands(monkeypatch):
+    """A sheet seen along its plane at 512 x 512 x 512 samples: many pixels list more leaves than a list holds.  The wave that
+    meets such a pixel in a batch of walks hands it on through the launch's queue of long pixels, and whichever wave draws next
+    traces it as an item of its own.  Frames rendered that way (batches of the default size and of 16 pixels), with every wave
+    keeping what it meets (RT_NO_LONG_QUEUE=1) and by the packet walk must be the same film, number for number: a pixel's sum
+    is one wave's, added in one order, whoever traces it."""
     from raytrace_amd import _lib
     lib = _lib.load()
     cam = phys.OrthographicCamera(LookFrom=(3.0, 0.0, 0.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 0.0, 1.0), FOVHeight=0.5, FOVWidth=2.2)
@@ -106,17 +107,17 @@ def test_tiles_with_long_lists_first_and_a_pixel_at_a_time(monkeypatch):
     sc = phys.Scene(Camera=[cam], Node=[phys.Node("sheet", phys.NewMesh(grid_mesh()), phys.Emitter(tex))],
                     RenderOptions=phys.RenderOptions(3, 512, 4, 512, 512))
     films = {}
-    for name, env in (("refined", {}), ("plain", {"RT_NO_ORDER_REFINE": "1"}), ("packet", {"RT_NO_BEAM": "1"})):
+    for name, env in (("queue", {}), ("queue16", {"RT_BEAM_WALK_PX": "16"}), ("kept", {"RT_NO_LONG_QUEUE": "1"}), ("packet", {"RT_NO_BEAM": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with phys.DeviceScene(sc) as dev:
-            films[name] = _film(dev, lib, sc, frames=3)  # pilot + 510 samples; 512 samples, whose launch is the one that learns; the frame from the refined schedule
+            films[name] = _film(dev, lib, sc, frames=2)  # pilot + 510 samples from the plain order; 512 samples from the schedule
         for k in env:
             monkeypatch.delenv(k)
-    assert films["refined"][1] == films["plain"][1] == films["packet"][1]
-    assert films["refined"][1][1] < films["refined"][1][0]  # something is hit
-    assert np.array_equal(films["refined"][0], films["plain"][0])
-    assert np.array_equal(films["refined"][0], films["packet"][0])
+    assert films["queue"][1] == films["queue16"][1] == films["kept"][1] == films["packet"][1]
+    assert films["queue"][1][1] < films["queue"][1][0]  # something is hit
+    for name in ("queue16", "kept", "packet"):
+        assert np.array_equal(films["queue"][0], films[name][0]), name
 
 
 def test_tiny_and_degenerate_meshes(monkeypatch):
