@@ -1293,11 +1293,22 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     VisitCounts vc{0, 0};
 #ifdef RT_WAVE_TIMES
     const unsigned long long wave_t0 = wall_clock64();
-    unsigned long long wave_items = 0;
+    unsigned long long wave_items = 0, wave_last_end = wave_t0, wave_last = 0, wave_prev = 0;
 #endif
     // Draws the next batch of one queue: tile number (or -1 when that queue is exhausted) and which batch of the tile.
+    // look_first: when the queues run out, every wave draws from all eight, and an atomic on one address is performed only some
+    // tens of millions of times a second, whereas a load is not held up by the others (it is a round trip more, though).
     const uint32_t walk_px = (uint32_t)pass.walk_px, n_batches = 64u / walk_px;  // batches per tile
-    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out) {
+    const uint32_t n_groups = (uint32_t)((n_tiles + 63) >> 6);
+    uint32_t drained = 0;  // (lane 0's) queues known to have run out, a bit each
+    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out, bool look_first) {
+        tile_out = -1;
+        if ((drained >> owner) & 1u) return;
+        const uint32_t all = (pass.order ? pass.queue_len[owner] : ((n_groups + 7u - owner) >> 3) * 64u) * n_batches;
+        if (look_first && __hip_atomic_load(&counters->tile_cursor[owner].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= all) {
+            drained |= 1u << owner;
+            return;
+        }
         const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
         const uint32_t idx = item / n_batches;
         sub_out = item - idx * n_batches;
@@ -1308,6 +1319,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
             cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
         }
         tile_out = (cand >= 0 && cand < n_tiles) ? cand : -1;
+        if (tile_out < 0) drained |= 1u << owner;
     };
     // The pixels that take milliseconds each (their list of leaves goes on beyond one instalment, and every round walks the tree
     // again) are not traced by the wave that meets them in a batch: it puts them into a queue of the launch, and a wave that is
@@ -1343,33 +1355,22 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     };
     const bool may_defer = walk_px > 1 && pass.beam_serial != 0 && n_tiles <= (1ll << 25);  // (an entry holds tile * 64 + pixel in 32 bits)
     int32_t* const walked = bt.walk_scratch + (size_t)blockIdx.x * (size_t)bt.walk_stride;
-    // the batch after the current one is drawn while the current one is traced (the atomic's round trip is off the critical path)
-    long long ahead_v = -1;
-    uint32_t ahead_sub = 0;
-    unsigned long long ahead_ht = 0;  // the long pixels' cursors, read when the batch ahead was drawn
+    unsigned long long seen_ht = 0;  // the long pixels' cursors as read after the last draw (while the batch was traced, the load was under way)
     bool pusher = may_defer;  // (lane 0's) this wave may still add to the queue of long pixels: it has not found the tile queues empty
     bool pushed = false;      // ... and has added to it
-    if (p == 0) draw(xcd, ahead_v, ahead_sub);
     for (;;) {
         long long v = -1;
         uint32_t sub = 0, px = 1, wpx = 1;
         if (p == 0) {
             bool tiles_left = true;
-            if (may_defer && draw_long(v, sub, ahead_ht)) {
+            if (may_defer && draw_long(v, sub, seen_ht)) {
                 // (px = wpx = 1)
-            } else if (ahead_v >= 0) {
-                v = ahead_v;
-                sub = ahead_sub;
-                px = (uint32_t)pass.block_px;
-                wpx = walk_px;
-                draw(xcd, ahead_v, ahead_sub);
-                if (may_defer) ahead_ht = glance();
-            } else {  // own queue exhausted (cursors only grow): take from the other XCDs' queues
-                for (uint32_t k = 1; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub);
-                if (may_defer) ahead_ht = glance();
-                px = (uint32_t)pass.block_px;
-                wpx = walk_px;
+            } else {  // a batch of this XCD's queue; when that has run out (cursors only grow), of the others'
+                for (uint32_t k = 0; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub, k > 0);
                 tiles_left = v >= 0;
+                px = (uint32_t)pass.block_px;
+                wpx = walk_px;
+                if (may_defer) seen_ht = glance();
             }
             if (!tiles_left && may_defer) {
                 // No batches left.  What this wave has put into the queue of long pixels is there (the fence), and whatever any wave
@@ -1409,19 +1410,26 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         px = (uint32_t)__builtin_amdgcn_readfirstlane((int)px);
         wpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wpx);
         const long long t_start = pass.cost ? clock64() : 0;
+#ifdef RT_WAVE_TIMES
+        const unsigned long long item_t0 = wall_clock64();
+#endif
         if (beam_walk_batch<PYR>(sc, cam, pass, v, (int)(sub * wpx), (int)wpx, walked, p, sc.stack_pairs, may_defer && wpx > 1, counters, bt.long_px, vc)) pushed = true;
         for (uint32_t part = 0; part * px < wpx; part++)
             beam_item<IMG, PYR>(sc, cam, pass, bt, film, v, sub * (wpx / px) + part, (int)px, walked, (int)(part * px), p, sc.stack_pairs, n_total, n_left, n_culled, vc);
         if (pass.cost && p == 0) atomicAdd(&pass.cost[v], (unsigned int)(clock64() - t_start));
 #ifdef RT_WAVE_TIMES
         wave_items++;
+        wave_last_end = wall_clock64();
+        wave_prev = wave_last;
+        wave_last = (wave_last_end - item_t0) | ((unsigned long long)(wpx == 1 ? 1 : 0) << 32);
 #endif
     }
 #ifdef RT_WAVE_TIMES
     if (p == 0 && blockIdx.x < 8192) {
-        g_wave_times[3 * blockIdx.x] = wave_t0;
-        g_wave_times[3 * blockIdx.x + 1] = wall_clock64();
-        g_wave_times[3 * blockIdx.x + 2] = wave_items;
+        g_wave_times[4 * blockIdx.x] = wave_t0;
+        g_wave_times[4 * blockIdx.x + 1] = wave_last_end;   // (the end of its last item: some waves stay on to look for long pixels)
+        g_wave_times[4 * blockIdx.x + 2] = wave_items | (wave_last << 16);
+        g_wave_times[4 * blockIdx.x + 3] = wave_prev;  // items; from bit 16: the last item's duration (32 bits), then 1 if it was a long pixel
     }
 #endif
     if (p == 0) {  // the tallies are per wave already
@@ -2178,6 +2186,7 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     const size_t walk_lane = 2 * (size_t)sc.stack_pairs * sizeof(int32_t);  // a walking lane's stack
     while (walk_px * 2 <= want_walk && walk_px * 2 <= kBeamWalkPixels && (size_t)(walk_px * 2) * walk_lane <= lds) walk_px *= 2;
     pd.walk_px = walk_px;
+    // The end of a scheduled queue in small batches: an eighth of it, at most what keeps the XCD's waves busy for a few large batches' time.
     if (!bt.walk_scratch || bt.walk_stride < beam_walk_stride() || !bt.long_px) return false;
     static std::atomic<uint32_t> serial{0};
     do pd.beam_serial = ++serial; while (pd.beam_serial == 0);
@@ -2286,9 +2295,9 @@ void launch_direct(const DScene& sc, const Queues& q, const StripeCounts& n_surf
 
 #ifdef RT_WAVE_TIMES
 void debug_wave_times(unsigned long long* out, bool reset) {  // out: 3 * 8192 values
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), 3 * 8192 * sizeof(unsigned long long));
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), 4 * 8192 * sizeof(unsigned long long));
     if (reset) {
-        static const unsigned long long zero[3 * 8192] = {};
+        static const unsigned long long zero[4 * 8192] = {};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_times), zero, sizeof(zero));
     }
 }

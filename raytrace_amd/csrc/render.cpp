@@ -18,6 +18,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "host_common.h"
@@ -400,11 +401,12 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& ge
     for (uint32_t c : cost)
         if (c) { sum += c; busy++; }
     const double mean = busy ? sum / (double)busy : 1.0;
-    // three classes only: the few tiles that cost several times the mean go first (they would otherwise end the
-    // launch with most of the chip idle); everything else keeps its spatial order and with it its L2 locality
+    // four classes only: the few tiles that cost several times the mean go first (they would otherwise end the
+    // launch with most of the chip idle) and the cheap ones last (the waves then end within a cheap batch's time of
+    // each other); everything else keeps its spatial order and with it its L2 locality
     auto klass = [&](int32_t t) {
         const double c = (double)cost[(size_t)t];
-        return c >= 4.0 * mean ? 2 : (c >= 2.0 * mean ? 1 : 0);
+        return c >= 4.0 * mean ? 2 : (c >= 2.0 * mean ? 1 : (c < 0.5 * mean ? -1 : 0));
     };
     for (int k = 0; k < 8; k++) {
         const size_t begin = order.size();
@@ -844,20 +846,20 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
 #ifdef RT_WAVE_TIMES
     {
         {  // when the persistent waves of the last k_beam launch began and ended
-            std::vector<unsigned long long> wt(3 * 8192);
+            std::vector<unsigned long long> wt(4 * 8192);
             debug_wave_times(wt.data(), true);
             unsigned long long t0 = ~0ull, t1 = 0;
             size_t n = 0;
             for (size_t i = 0; i < 8192; i++)
-                if (wt[3 * i + 1]) { t0 = std::min(t0, wt[3 * i]); t1 = std::max(t1, wt[3 * i + 1]); n++; }
+                if (wt[4 * i + 1]) { t0 = std::min(t0, wt[4 * i]); t1 = std::max(t1, wt[4 * i + 1]); n++; }
             if (n) {
                 std::vector<double> ends, starts;
                 unsigned long long items_min = ~0ull, items_max = 0;
                 for (size_t i = 0; i < 8192; i++)
-                    if (wt[3 * i + 1]) {
-                        ends.push_back((double)(wt[3 * i + 1] - t0) * 1e-5);   // ms at 100 MHz
-                        starts.push_back((double)(wt[3 * i] - t0) * 1e-5);
-                        items_min = std::min(items_min, wt[3 * i + 2]); items_max = std::max(items_max, wt[3 * i + 2]);
+                    if (wt[4 * i + 1]) {
+                        ends.push_back((double)(wt[4 * i + 1] - t0) * 1e-5);   // ms at 100 MHz
+                        starts.push_back((double)(wt[4 * i] - t0) * 1e-5);
+                        items_min = std::min(items_min, wt[4 * i + 2] & 0xffff); items_max = std::max(items_max, wt[4 * i + 2] & 0xffff);
                     }
                 std::sort(ends.begin(), ends.end());
                 std::sort(starts.begin(), starts.end());
@@ -866,6 +868,15 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 for (double t : starts) late += t > 0.5 * ends.back();
                 fprintf(stderr, "[rt] k_beam waves %zu (%zu of them started in the second half of the launch: not resident before): start (ms) median %.3f last %.3f; end (ms) first %.3f 10%% %.3f median %.3f 90%% %.3f 99%% %.3f last %.3f; items per wave %llu..%llu\n",
                         n, late, q(starts, 0.5), starts.back(), ends.front(), q(ends, 0.1), q(ends, 0.5), q(ends, 0.9), q(ends, 0.99), ends.back(), items_min, items_max);
+                std::vector<std::tuple<double, unsigned long long, unsigned long long>> lastw;
+                for (size_t i = 0; i < 8192; i++)
+                    if (wt[4 * i + 1]) lastw.push_back({(double)(wt[4 * i + 1] - t0) * 1e-5, wt[4 * i + 2], wt[4 * i + 3]});
+                std::sort(lastw.begin(), lastw.end());
+                fprintf(stderr, "[rt] k_beam waves, the last to end (end ms / their last item's ms / the one before's; L = a long pixel):");
+                for (size_t i = lastw.size() > 24 ? lastw.size() - 24 : 0; i < lastw.size(); i++)
+                    fprintf(stderr, " %.3f/%.3f%s/%.3f%s", std::get<0>(lastw[i]), (double)((std::get<1>(lastw[i]) >> 16) & 0xffffffffull) * 1e-5, ((std::get<1>(lastw[i]) >> 48) & 1) ? "L" : "",
+                            (double)(std::get<2>(lastw[i]) & 0xffffffffull) * 1e-5, ((std::get<2>(lastw[i]) >> 32) & 1) ? "L" : "");
+                fprintf(stderr, "\n");
             }
         }
     }
