@@ -35,6 +35,7 @@ struct PassDesc {
     const int32_t* order;
     uint32_t* cost;
     uint32_t queue_off[8], queue_len[8];
+    uint32_t queue_cheap[8];        // that many tiles at the end of each queue cost little (k_beam hands them out once the others of ALL queues are gone)
 };
 
 struct Queues {

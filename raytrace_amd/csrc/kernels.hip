@@ -1293,25 +1293,35 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     VisitCounts vc{0, 0};
 #ifdef RT_WAVE_TIMES
     const unsigned long long wave_t0 = wall_clock64();
-    unsigned long long wave_items = 0, wave_last_end = wave_t0, wave_last = 0, wave_prev = 0;
+    unsigned long long wave_items = 0, wave_last_end = wave_t0, wave_last = 0, wave_prev = 0, wave_last_tile = 0;
 #endif
     // Draws the next batch of one queue: tile number (or -1 when that queue is exhausted) and which batch of the tile.
     // look_first: when the queues run out, every wave draws from all eight, and an atomic on one address is performed only some
     // tens of millions of times a second, whereas a load is not held up by the others (it is a round trip more, though).
     const uint32_t walk_px = (uint32_t)pass.walk_px, n_batches = 64u / walk_px;  // batches per tile
     const uint32_t n_groups = (uint32_t)((n_tiles + 63) >> 6);
-    uint32_t drained = 0;  // (lane 0's) queues known to have run out, a bit each
-    auto draw = [&](uint32_t owner, long long& tile_out, uint32_t& sub_out, bool look_first) {
+    // A scheduled queue ends with its cheap tiles (queue_cheap of them), which have a cursor of their own (`cheap`): they are
+    // taken up when the others of ALL queues are gone, so that the batches still under way when the work runs out are short ones.
+    uint32_t drained = 0;  // (lane 0's) queues known to have run out, a bit each; from bit 8: their cheap ends
+    auto draw = [&](uint32_t owner, bool cheap, long long& tile_out, uint32_t& sub_out, bool look_first) {
         tile_out = -1;
-        if ((drained >> owner) & 1u) return;
-        const uint32_t all = (pass.order ? pass.queue_len[owner] : ((n_groups + 7u - owner) >> 3) * 64u) * n_batches;
-        if (look_first && __hip_atomic_load(&counters->tile_cursor[owner].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= all) {
-            drained |= 1u << owner;
+        const uint32_t bit = 1u << (owner + (cheap ? 8u : 0u));
+        if (drained & bit) return;
+        const uint32_t n_cheap = pass.order ? pass.queue_cheap[owner] : 0u;
+        const uint32_t n_dear = (pass.order ? pass.queue_len[owner] : ((n_groups + 7u - owner) >> 3) * 64u) - n_cheap;
+        const uint32_t all = (cheap ? n_cheap : n_dear) * n_batches;
+        unsigned int* const cursor = cheap ? &counters->cheap_cursor[owner].v : &counters->tile_cursor[owner].v;
+        if (all == 0 || (look_first && __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= all)) {
+            drained |= bit;
             return;
         }
-        const uint32_t item = atomicAdd(&counters->tile_cursor[owner].v, 1u);
-        const uint32_t idx = item / n_batches;
-        sub_out = item - idx * n_batches;
+        const uint32_t item = atomicAdd(cursor, 1u);
+        if (item >= all) {
+            drained |= bit;
+            return;
+        }
+        const uint32_t idx = (cheap ? n_dear : 0u) + item / n_batches;
+        sub_out = item % n_batches;
         long long cand = -1;
         if (pass.order) {
             if (idx < pass.queue_len[owner]) cand = pass.order[pass.queue_off[owner] + idx];
@@ -1319,7 +1329,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
             cand = ((long long)(idx >> 6) * 8 + owner) * 64 + (idx & 63);
         }
         tile_out = (cand >= 0 && cand < n_tiles) ? cand : -1;
-        if (tile_out < 0) drained |= 1u << owner;
+        if (tile_out < 0) drained |= bit;
     };
     // The pixels that take milliseconds each (their list of leaves goes on beyond one instalment, and every round walks the tree
     // again) are not traced by the wave that meets them in a batch: it puts them into a queue of the launch, and a wave that is
@@ -1366,7 +1376,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
             if (may_defer && draw_long(v, sub, seen_ht)) {
                 // (px = wpx = 1)
             } else {  // a batch of this XCD's queue; when that has run out (cursors only grow), of the others'
-                for (uint32_t k = 0; k < 8 && v < 0; k++) draw((xcd + k) & 7, v, sub, k > 0);
+                for (uint32_t k = 0; k < 16 && v < 0; k++) draw((xcd + k) & 7, k >= 8, v, sub, (k & 7) > 0);
                 tiles_left = v >= 0;
                 px = (uint32_t)pass.block_px;
                 wpx = walk_px;
@@ -1421,6 +1431,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         wave_items++;
         wave_last_end = wall_clock64();
         wave_prev = wave_last;
+        wave_last_tile = (unsigned long long)v * 64 + sub * wpx;
         wave_last = (wave_last_end - item_t0) | ((unsigned long long)(wpx == 1 ? 1 : 0) << 32);
 #endif
     }
@@ -1429,7 +1440,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         g_wave_times[4 * blockIdx.x] = wave_t0;
         g_wave_times[4 * blockIdx.x + 1] = wave_last_end;   // (the end of its last item: some waves stay on to look for long pixels)
         g_wave_times[4 * blockIdx.x + 2] = wave_items | (wave_last << 16);
-        g_wave_times[4 * blockIdx.x + 3] = wave_prev;  // items; from bit 16: the last item's duration (32 bits), then 1 if it was a long pixel
+        g_wave_times[4 * blockIdx.x + 3] = (wave_prev & 0xffffffull) | ((unsigned long long)wave_last_tile << 24);  // items; from bit 16: the last item's duration (32 bits), then 1 if it was a long pixel
     }
 #endif
     if (p == 0) {  // the tallies are per wave already
@@ -2178,10 +2189,10 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     lds += fixed + (size_t)cands * per_leaf;
     // Pixels walked together: as many lanes as the LDS has room for their stacks (before the lists are needed),
     // for a frame or a large share of one; an item's own for a small share, whose launch wants many small pieces of work.
-    // Measured with 4 / 8 / 16 pixels per walk, ms per launch: the 4K scan frame 69.0 / 64.4 / 62.1, a quarter of it - / 16.6 / 16.4, an
-    // eighth 9.2 / 8.75 / 9.2; the same scene at 1920x1080 21.1 / 20.1 / 20.3, a quarter of that 5.7 / 5.7 / 6.7, an eighth 4.7 / 4.8 / 5.8.
+    // Measured with 4 / 8 / 16 pixels per walk, ms per launch: the 4K scan frame 67.0 / 62.9 / 60.9, a quarter of it - / 16.2 / 15.6, an
+    // eighth - / 8.40 / 8.14; the same scene at 1920x1080 20.3 / 19.1 / 18.6, a quarter of that 5.96 / 6.18 / 6.49, an eighth 4.74 / 5.05 / 5.24.
     int walk_px = pass.block_px;
-    int want_walk = pass.n_pixels >= 2000000 ? 16 : (pass.n_pixels >= 700000 ? 8 : pass.block_px);
+    int want_walk = pass.n_pixels >= 700000 ? 16 : pass.block_px;
     if (const char* e = getenv("RT_BEAM_WALK_PX")) want_walk = atoi(e);  // tuning knob
     const size_t walk_lane = 2 * (size_t)sc.stack_pairs * sizeof(int32_t);  // a walking lane's stack
     while (walk_px * 2 <= want_walk && walk_px * 2 <= kBeamWalkPixels && (size_t)(walk_px * 2) * walk_lane <= lds) walk_px *= 2;

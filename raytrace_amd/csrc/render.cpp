@@ -54,7 +54,7 @@ struct WorkBuffers {
     size_t order_tiles = 0;
     std::string order_key;
     bool order_valid = false;
-    uint32_t queue_off[8] = {}, queue_len[8] = {};
+    uint32_t queue_off[8] = {}, queue_len[8] = {}, queue_cheap[8] = {};
     uint64_t culled_pixels = 0;  // pixels of the tiles the schedule leaves out (outside the screen bounds of the scene)
     bool is_static = false;      // the buffers live in the library's static scratch: nothing to allocate, grow or free
 };
@@ -193,7 +193,7 @@ int ensure_work(const rt_scene* sc, Replica& rep, uint64_t want_paths) {
         std::swap(w->order_key, old->order_key);
         std::swap(w->order_valid, old->order_valid);
         std::swap(w->culled_pixels, old->culled_pixels);
-        for (int k = 0; k < 8; k++) { std::swap(w->queue_off[k], old->queue_off[k]); std::swap(w->queue_len[k], old->queue_len[k]); }
+        for (int k = 0; k < 8; k++) { std::swap(w->queue_off[k], old->queue_off[k]); std::swap(w->queue_len[k], old->queue_len[k]); std::swap(w->queue_cheap[k], old->queue_cheap[k]); }
         destroy_work(old);
     }
     rep.work = w;
@@ -402,11 +402,29 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& ge
         if (c) { sum += c; busy++; }
     const double mean = busy ? sum / (double)busy : 1.0;
     // four classes only: the few tiles that cost several times the mean go first (they would otherwise end the
-    // launch with most of the chip idle) and the cheap ones last (the waves then end within a cheap batch's time of
-    // each other); everything else keeps its spatial order and with it its L2 locality
+    // launch with most of the chip idle) and the cheap ones last (k_beam takes those up when the others of all queues
+    // are gone: the waves then end within a cheap batch's time of each other); everything else keeps its spatial order
+    // and with it its L2 locality
+    // (Cheap: under half the mean, and so are the eight tiles around it.  A tile at the mesh's outline costs the pilot's
+    // packets little, few of its pixels seeing anything, but those that do see faces edge-on: the dearest pixels of k_beam.)
+    const int tw = geo.groups_x * 8;
+    const int th = (int)(((tiles_total + 63) / 64 + geo.groups_x - 1) / geo.groups_x) * 8;
+    std::vector<uint8_t> low((size_t)tw * (size_t)th, 1);
+    auto place = [&](int64_t t) {
+        const int64_t group = t >> 6;
+        const int w8 = (int)(t & 63);
+        return (size_t)((int)(group / geo.groups_x) * 8 + (w8 >> 3)) * (size_t)tw + (size_t)((int)(group % geo.groups_x) * 8 + (w8 & 7));
+    };
+    for (int64_t t = 0; t < tiles_total; t++) low[place(t)] = (double)cost[(size_t)t] < 0.5 * mean;
     auto klass = [&](int32_t t) {
         const double c = (double)cost[(size_t)t];
-        return c >= 4.0 * mean ? 2 : (c >= 2.0 * mean ? 1 : (c < 0.5 * mean ? -1 : 0));
+        if (c >= 2.0 * mean) return c >= 4.0 * mean ? 2 : 1;
+        const size_t at = place(t);
+        const int x = (int)(at % (size_t)tw), y = (int)(at / (size_t)tw);
+        for (int yy = std::max(0, y - 1); yy <= std::min(th - 1, y + 1); yy++)
+            for (int xx = std::max(0, x - 1); xx <= std::min(tw - 1, x + 1); xx++)
+                if (!low[(size_t)yy * (size_t)tw + (size_t)xx]) return 0;
+        return -1;
     };
     for (int k = 0; k < 8; k++) {
         const size_t begin = order.size();
@@ -420,6 +438,16 @@ int build_tile_order(WorkBuffers& w, int64_t tiles_total, const TileGeometry& ge
         std::stable_sort(order.begin() + begin, order.end(), [&](int32_t a, int32_t b) { return klass(a) > klass(b); });
         w.queue_off[k] = (uint32_t)begin;
         w.queue_len[k] = (uint32_t)(order.size() - begin);
+        w.queue_cheap[k] = (uint32_t)std::count_if(order.begin() + begin, order.end(), [&](int32_t t) { return klass(t) < 0; });
+    }
+    if (std::getenv("RT_DEBUG")) {
+        std::vector<uint32_t> sorted(cost);
+        std::sort(sorted.begin(), sorted.end());
+        size_t n_class[4] = {0, 0, 0, 0};
+        for (int32_t t : order) n_class[klass(t) + 1]++;
+        auto at = [&](double f) { return sorted[(size_t)(f * (double)(sorted.size() - 1))]; };
+        fprintf(stderr, "[rt] tile schedule: %zu tiles, pilot cost mean %.0f (of the %zu that cost anything), percentiles 10/25/50/75/90/99: %u %u %u %u %u %u; classes cheap/plain/dear/dearest: %zu %zu %zu %zu\n",
+                order.size(), mean, busy, at(0.1), at(0.25), at(0.5), at(0.75), at(0.9), at(0.99), n_class[0], n_class[1], n_class[2], n_class[3]);
     }
     HIP_TRY(hipMemcpyAsync(w.tile_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));  // `order` goes out of scope
@@ -720,7 +748,7 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
             const bool whole = t0 == 0 && nt == tiles_total;
             pass.order = (want_order && w.order_valid && whole) ? w.tile_order : nullptr;
             pass.cost = (pilot && whole) ? w.tile_cost : nullptr;
-            for (int k = 0; k < 8; k++) { pass.queue_off[k] = w.queue_off[k]; pass.queue_len[k] = w.queue_len[k]; }
+            for (int k = 0; k < 8; k++) { pass.queue_off[k] = w.queue_off[k]; pass.queue_len[k] = w.queue_len[k]; pass.queue_cheap[k] = w.queue_cheap[k]; }
             if (pass.cost) HIP_TRY(hipMemsetAsync(w.tile_cost, 0, (size_t)tiles_total * sizeof(uint32_t), stream));
             if (int rc = reset_cursors()) return rc;
             EventPair* ev = nullptr;
@@ -874,8 +902,11 @@ int render_into_film(rt_scene* sc, Replica& rep, const rt_camera_desc* camera, c
                 std::sort(lastw.begin(), lastw.end());
                 fprintf(stderr, "[rt] k_beam waves, the last to end (end ms / their last item's ms / the one before's; L = a long pixel):");
                 for (size_t i = lastw.size() > 24 ? lastw.size() - 24 : 0; i < lastw.size(); i++)
-                    fprintf(stderr, " %.3f/%.3f%s/%.3f%s", std::get<0>(lastw[i]), (double)((std::get<1>(lastw[i]) >> 16) & 0xffffffffull) * 1e-5, ((std::get<1>(lastw[i]) >> 48) & 1) ? "L" : "",
-                            (double)(std::get<2>(lastw[i]) & 0xffffffffull) * 1e-5, ((std::get<2>(lastw[i]) >> 32) & 1) ? "L" : "");
+                    {
+                    const unsigned long long px = std::get<2>(lastw[i]) >> 24, tl = px >> 6, grp = tl >> 6;
+                    fprintf(stderr, " %.3f/%.3f%s/%.3f@%d,%d+%d(cost %u)", std::get<0>(lastw[i]), (double)((std::get<1>(lastw[i]) >> 16) & 0xffffffffull) * 1e-5, ((std::get<1>(lastw[i]) >> 48) & 1) ? "L" : "",
+                            (double)(std::get<2>(lastw[i]) & 0xffffffull) * 1e-5, (int)(grp % (unsigned long long)pass.groups_x) * 8 + (int)(tl & 7), (int)(grp / (unsigned long long)pass.groups_x) * 8 + (int)((tl >> 3) & 7), (int)(px & 63), 0u);
+                }
                 fprintf(stderr, "\n");
             }
         }

@@ -253,6 +253,7 @@ struct Counters {
     struct alignas(128) LongPixels {           // k_beam: the queue BeamTables::long_px
         unsigned long long head_tail;          // entries taken (low half) and entries reserved (high half): one load reads both
     } long_px;
+    Cursor cheap_cursor[8];                    // k_beam: next of the cheap tiles at the end of each XCD's share
     Cursor long_done[8];                       // k_beam: waves of each XCD that have found the tile queues empty, and so add nothing more to that queue
 };
 
