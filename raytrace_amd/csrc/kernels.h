@@ -21,6 +21,7 @@ struct PassDesc {
     int32_t acc_offset;             // primary launch: where the pixels' running sums start in dynamic LDS, in dwords (set by launch_primary)
     int32_t beam_offset;            // ... and where the pixel beams' lists and walk states start (set by launch_beam)
     int32_t beam_cands;             // pixel beams: leaves a pixel's list holds at a time (set by launch_beam)
+    uint32_t long_cap;              // pixel beams: entries of BeamTables::long_px a launch may use (set by launch_beam); a wave that finds them used up traces its long pixels itself
     uint32_t beam_serial;           // pixel beams: number of the launch (set by launch_beam): marks the entries of BeamTables::long_px that belong to it; 0: that queue is not used
     int32_t walk_px;                // pixel beams: pixels whose trees are walked together, a lane each: block_px times a power of two, at most 16 (set by launch_beam)
     int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group

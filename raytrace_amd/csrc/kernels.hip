@@ -1016,7 +1016,7 @@ RT_DEV bool beam_walk_batch(const DScene& sc, const DCamera& cam, const PassDesc
                     found |= 0x100;
                     if (defer) {  // such a pixel takes milliseconds: not one of several of an item, but an item of its own for the wave that draws next (k_beam)
                         const uint32_t slot = (uint32_t)(atomicAdd(&counters->long_px.head_tail, 1ull << 32) >> 32);
-                        if (slot < kBeamLongCap) {
+                        if (slot < pass.long_cap) {
                             atomicExch(&long_px[slot], ((unsigned long long)pass.beam_serial << 32) | (unsigned long long)(uint32_t)(v * 64 + pix));
                             found = 0x200;  // nothing listed, and beam_item leaves the pixel alone
                             handed_on = true;
@@ -1350,7 +1350,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
         for (;;) {
             slot = (uint32_t)ht;
             const uint32_t reserved = (uint32_t)(ht >> 32);
-            if (slot >= (reserved < kBeamLongCap ? reserved : kBeamLongCap)) return false;
+            if (slot >= (reserved < pass.long_cap ? reserved : pass.long_cap)) return false;
             const unsigned long long seen = atomicCAS(&counters->long_px.head_tail, ht, ht + 1);  // (fails whenever another wave took or added one: so many retries at most)
             if (seen == ht) break;
             ht = seen;
@@ -2207,6 +2207,8 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     if (!bt.walk_scratch || bt.walk_stride < beam_walk_stride() || !bt.long_px) return false;
     static std::atomic<uint32_t> serial{0};
     do pd.beam_serial = ++serial; while (pd.beam_serial == 0);
+    pd.long_cap = kBeamLongCap;
+    if (const char* e = getenv("RT_BEAM_LONG_CAP")) pd.long_cap = (uint32_t)std::min<long long>(kBeamLongCap, std::max(0ll, atoll(e)));  // test knob: a queue that runs full
     if (getenv("RT_NO_LONG_QUEUE")) pd.beam_serial = 0;  // test knob: every wave traces the pixels with long lists that it meets
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
