@@ -1070,6 +1070,15 @@ RT_DEV void beam_setup_pyr(const DCamera& cam, V3 org, int32_t dx_img, int32_t d
     state[14] = 0;
 }
 
+// Rewinds a walk that beam_setup / beam_setup_pyr has set up (and beam_fill may have advanced) to its start: the walk's own
+// part of the state is the node it is at, the stack's height and that node's entry distance.
+template <bool PYR>
+RT_DEV void beam_restart(int32_t* state) {
+    state[12] = 0;
+    state[13] = 0;
+    state[14] = PYR ? 0 : state[9];
+}
+
 // One instalment of a pixel's walk: up to `cands` leaves, (reference, entry distance, face mask) triples in cand.  The
 // walk is over when state[12] == kFastEmpty afterwards.  stack: this lane's own 2 * cap dwords.  `scale` turns the entry
 // parameter into a distance no ray of the bundle undercuts (1 for parallel rays).

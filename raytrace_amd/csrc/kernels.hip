@@ -1156,6 +1156,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         // leaves from `beam_resume` on, face data from memory
         const int n_compact = __builtin_amdgcn_readfirstlane(px_state[25]);
         const int beam_resume = __builtin_amdgcn_readfirstlane(px_state[46]);
+        const bool use_compact = !beam_long;
         const int32_t* const px_compact = beam_compact + pb * kBeamFacesMax * kBeamFaceDwords;
         const double beam_T = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[11]) << 32) |
                                                                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[10])));
@@ -1170,6 +1171,14 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         const float scale = PYR ? __int_as_float(__builtin_amdgcn_readfirstlane(px_state[45])) : 1.0f;
         const double xd = (double)lx, yd = (double)y;
         const uint32_t ctr0 = (uint32_t)(y * pass.dx + lx);
+        if (beam_long) {
+            // The whole state of the pixel's walk, once (the batch's walk handed on only what the thinning and the rounds of other
+            // pixels read); a round then only rewinds it.  In the rounds themselves the compiler moved the set-up's divisions
+            // ahead of the rounds of EVERY pixel and spilled the results.
+            if (p == pb) setup(lx, y, px_state);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         V3 acc = mk(0, 0, 0);
 #ifdef RT_VISIT_STATS
         const long long px_t0 = clock64();
@@ -1177,97 +1186,90 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         if (beam_long) RT_STAT(5, 1);                      // ... whose list goes on beyond one instalment
         if (!beam_long && beam_resume < beam_first) RT_STAT(6, 1);     // ... with more survivors than the compact array holds
 #endif
-        // The rounds, compiled twice: a pixel with a complete list never walks, and the code of the walk -- with what the compiler
-        // moves out of it, ahead of the rounds -- stays out of its way.
-        auto run_rounds = [&](auto long_list) {
-            constexpr bool LONG = decltype(long_list)::value;
-            for (int round = 0; round < rounds; round++) {
-                const int k = (round << 6) + p;
-                const bool traced = k < pass.sample_count;
-                const int left_here = pass.sample_count - (round << 6);
-                n_total += (uint32_t)(left_here < 64 ? left_here : 64);
-                // the two jitter draws: draws 0 and 1 of the stream (pixel, sample, path 1), one Philox block.  The key schedule is
-                // rebuilt from the seed in every round (scalar additions): kept across the rounds it would occupy twenty scalar
-                // registers that the list walk needs.
-                uint32_t k0 = pass.seed_lo, k1 = pass.seed_hi;
-                asm volatile("" : "+s"(k0), "+s"(k1));
-                uint32_t blk[4] = {ctr0, (uint32_t)(pass.sample_begin + k), 1u, 0u};
-                philox4x32_10(blk, k0, k1);
-                const double fs = div_by(xd + draw53(blk[0], blk[1]), (double)pass.dx, inv_dx);  // render.go:202-210
-                const double ft = div_by(yd + draw53(blk[2], blk[3]), (double)pass.dy, inv_dy);
-                V3 o, d;
-                float fx, fy, fz;
-                if (PYR) {  // camera_pinhole.go:20-34 (camera_focusable.go:26-63 with a lens of radius 0: the same from LookFrom)
-                    const V3 ip = (ld3(cam.llc) + ld3(cam.horizontal) * fs) + ld3(cam.vertical) * ft;
-                    o = org;
-                    d = unit(ip - o);
-                    fx = (float)d.x; fy = (float)d.y; fz = (float)d.z;
-                } else {  // camera_orthographic.go:24-46
-                    o = (ld3(cam.from) + ld3(cam.u) * (cam.fov_w * (fs - 0.5))) + ld3(cam.v) * (cam.fov_h * (ft - 0.5));
-                    d = d_all;
-                    fx = (float)(o.x + shift.x); fy = (float)(o.y + shift.y); fz = (float)(o.z + shift.z);
-                }
-                bool sound = traced && d_sound;
-                if (!bt.safe_camera) sound = sound && !(PYR ? bad3(d) : bad3(o));  // render.go:147-150
-                BeamHit bh{false, __builtin_inff(), 0, kMaxFloat, 0, 0};
-                bool walking = LONG;  // wave-uniform
-                if (walking && p == pb) setup(lx, y, px_state);  // this round's walk starts over
+        for (int round = 0; round < rounds; round++) {
+            const int k = (round << 6) + p;
+            const bool traced = k < pass.sample_count;
+            const int left_here = pass.sample_count - (round << 6);
+            n_total += (uint32_t)(left_here < 64 ? left_here : 64);
+            // the two jitter draws: draws 0 and 1 of the stream (pixel, sample, path 1), one Philox block.  The key schedule is
+            // rebuilt from the seed in every round (scalar additions): kept across the rounds it would occupy twenty scalar
+            // registers that the list walk needs.
+            uint32_t k0 = pass.seed_lo, k1 = pass.seed_hi;
+            asm volatile("" : "+s"(k0), "+s"(k1));
+            uint32_t blk[4] = {ctr0, (uint32_t)(pass.sample_begin + k), 1u, 0u};
+            philox4x32_10(blk, k0, k1);
+            const double fs = div_by(xd + draw53(blk[0], blk[1]), (double)pass.dx, inv_dx);  // render.go:202-210
+            const double ft = div_by(yd + draw53(blk[2], blk[3]), (double)pass.dy, inv_dy);
+            V3 o, d;
+            float fx, fy, fz;
+            if (PYR) {  // camera_pinhole.go:20-34 (camera_focusable.go:26-63 with a lens of radius 0: the same from LookFrom)
+                const V3 ip = (ld3(cam.llc) + ld3(cam.horizontal) * fs) + ld3(cam.vertical) * ft;
+                o = org;
+                d = unit(ip - o);
+                fx = (float)d.x; fy = (float)d.y; fz = (float)d.z;
+            } else {  // camera_orthographic.go:24-46
+                o = (ld3(cam.from) + ld3(cam.u) * (cam.fov_w * (fs - 0.5))) + ld3(cam.v) * (cam.fov_h * (ft - 0.5));
+                d = d_all;
+                fx = (float)(o.x + shift.x); fy = (float)(o.y + shift.y); fz = (float)(o.z + shift.z);
+            }
+            bool sound = traced && d_sound;
+            if (!bt.safe_camera) sound = sound && !(PYR ? bad3(d) : bad3(o));  // render.go:147-150
+            BeamHit bh{false, __builtin_inff(), 0, kMaxFloat, 0, 0};
+            bool walking = beam_long;  // wave-uniform
+            if (walking && p == pb) beam_restart<PYR>(px_state);  // this round's walk starts over
 #ifdef RT_VISIT_STATS
-                const long long faces_t0 = clock64();
+            const long long faces_t0 = clock64();
 #endif
-                if (!LONG) {
-                    beam_test_compact<PYR>(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, bh);
-                    if (beam_resume < beam_first)
-                        beam_test_prepared<PYR>(bt, o, d, fx, fy, fz, beam_T, px_cand + 3 * beam_resume, beam_first - beam_resume, true, kEps, sound, bh);
-                } else do {
-                    int n = beam_first;
-                    if (walking) {
+            if (use_compact) {
+                beam_test_compact<PYR>(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, bh);
+                if (beam_resume < beam_first)
+                    beam_test_prepared<PYR>(bt, o, d, fx, fy, fz, beam_T, px_cand + 3 * beam_resume, beam_first - beam_resume, true, kEps, sound, bh);
+            } else do {
+                int n = beam_first;
+                if (walking) {
 #ifdef RT_VISIT_STATS
-                        uint32_t again = 0;
-                        if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, cands, vc.overflow, scale, again);
+                    uint32_t again = 0;
+                    if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, cands, vc.overflow, scale, again);
 #else
-                        if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, cands, vc.overflow, scale);
+                    if (p == pb) px_state[15] = beam_fill<Slabs>(tree, px_state, dyn_lds + pb * 2 * cap, cap, px_cand, cands, vc.overflow, scale);
 #endif
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        n = __builtin_amdgcn_readfirstlane(px_state[15]);
-                    }
-                    if (n > 0) beam_test_prepared<PYR>(bt, o, d, fx, fy, fz, beam_T, px_cand, n, !LONG, kEps, sound, bh);
-                    if (walking) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        walking = __builtin_amdgcn_readfirstlane(px_state[12]) != kFastEmpty;
-                    }
-                } while (walking);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    n = __builtin_amdgcn_readfirstlane(px_state[15]);
+                }
+                if (n > 0) beam_test_prepared<PYR>(bt, o, d, fx, fy, fz, beam_T, px_cand, n, !beam_long, kEps, sound, bh);
+                if (walking) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    walking = __builtin_amdgcn_readfirstlane(px_state[12]) != kFastEmpty;
+                }
+            } while (walking);
 #ifdef RT_VISIT_STATS
-                RT_STAT(12, clock64() - faces_t0);
-                RT_STAT(10, 1);
+            RT_STAT(12, clock64() - faces_t0);
+            RT_STAT(10, 1);
 #endif
-                n_left += (uint32_t)__popcll(__ballot(sound && !bh.hit));  // render.go:170-173
-                if (sound && bh.hit) {
-                    if (IMG) {  // Face.Collide's texture coordinates (shape_mesh.go:131-140), Emitter.Resolve (material_emitter.go:22-25) with radiance (1, 1, 1)
-                        const double* uv6 = bt.uv + (size_t)bh.prim * 6;
-                        const double wgt = 1 - bh.u - bh.v;
-                        const double cu = (uv6[0] * wgt + uv6[2] * bh.u) + uv6[4] * bh.v;
-                        const double cv = (uv6[1] * wgt + uv6[3] * bh.u) + uv6[5] * bh.v;
-                        const V3 em = image_at_uniform(img_px, img_w, img_h, img_format, img_interp, img_wrap, cu, cv);
-                        acc.x += em.x; acc.y += em.y; acc.z += em.z;
-                    } else {  // any other emitting material, through the code every other kernel runs
-                        SceneHit h;
-                        h.c.t = bh.t; h.c.u = bh.u; h.c.v = bh.v;
-                        h.node = 0;
-                        h.leaf = bh.prim;
-                        h.rec_leaf = bh.prim;
-                        h.prim = sc.prim_face[m.prim_off + bh.prim];
-                        V3 em;
-                        const Ray r{o, d};
-                        if (after_closest(sc, r, mk(1, 1, 1), true, h, em) == 1) { acc.x += em.x; acc.y += em.y; acc.z += em.z; }
-                    }
+            n_left += (uint32_t)__popcll(__ballot(sound && !bh.hit));  // render.go:170-173
+            if (sound && bh.hit) {
+                if (IMG) {  // Face.Collide's texture coordinates (shape_mesh.go:131-140), Emitter.Resolve (material_emitter.go:22-25) with radiance (1, 1, 1)
+                    const double* uv6 = bt.uv + (size_t)bh.prim * 6;
+                    const double wgt = 1 - bh.u - bh.v;
+                    const double cu = (uv6[0] * wgt + uv6[2] * bh.u) + uv6[4] * bh.v;
+                    const double cv = (uv6[1] * wgt + uv6[3] * bh.u) + uv6[5] * bh.v;
+                    const V3 em = image_at_uniform(img_px, img_w, img_h, img_format, img_interp, img_wrap, cu, cv);
+                    acc.x += em.x; acc.y += em.y; acc.z += em.z;
+                } else {  // any other emitting material, through the code every other kernel runs
+                    SceneHit h;
+                    h.c.t = bh.t; h.c.u = bh.u; h.c.v = bh.v;
+                    h.node = 0;
+                    h.leaf = bh.prim;
+                    h.rec_leaf = bh.prim;
+                    h.prim = sc.prim_face[m.prim_off + bh.prim];
+                    V3 em;
+                    const Ray r{o, d};
+                    if (after_closest(sc, r, mk(1, 1, 1), true, h, em) == 1) { acc.x += em.x; acc.y += em.y; acc.z += em.z; }
                 }
             }
-        };
-        if (beam_long) run_rounds(std::true_type{});
-        else run_rounds(std::false_type{});
+        }
 #ifdef RT_VISIT_STATS
         RT_STAT(9, clock64() - px_t0);                                       // cycles in the rounds of all pixels
         if (beam_long) RT_STAT(8, clock64() - px_t0);                        // ... of the pixels with long lists
@@ -1392,7 +1394,8 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
                 // No batches left.  What this wave has put into the queue of long pixels is there (the fence), and whatever any wave
                 // still puts there that wave will find when it comes here, so a wave that finds the queue empty may go.  But the
                 // last batches' long pixels are better shared: some of the waves (512: more would only crowd the memory channel
-                // of the cursors) stay until no wave can add any more, looking every few microseconds, a hundred thousand times at most.
+                // of the cursors) stay until no wave can add any more, looking every few microseconds, twenty thousand times at most (a
+                // quarter of a second: the wait must end by itself should this grid ever share the chip and not be resident as a whole).
                 if (pusher) {
                     __threadfence();
                     atomicAdd(&counters->long_done[xcd].v, 1u);
@@ -1405,7 +1408,7 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
                         n += surely ? atomicAdd(&counters->long_done[k].v, 0u) : __hip_atomic_load(&counters->long_done[k].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     return n >= gridDim.x;
                 };
-                for (int look = 0; look < 100000; look++) {
+                for (int look = 0; look < 20000; look++) {
                     // (a wave that has added nothing may go on a glance; one that has must see its own additions)
                     if (draw_long(v, sub, (look == 0 && pushed) ? look_up() : glance()) || !stays) break;
                     if (all_done(false) && all_done(true)) {
