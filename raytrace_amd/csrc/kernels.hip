@@ -1160,7 +1160,9 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
         const int32_t* const px_compact = beam_compact + pb * kBeamFacesMax * kBeamFaceDwords;
         const double beam_T = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[11]) << 32) |
                                                                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(px_state[10])));
-        if (pass.cull_pixels && found == 0) {  // nothing listed: no ray through this pixel can hit, whatever its jitter
+        // nothing listed: no ray through this pixel can hit, whatever its jitter -- and every one of them leaves the scene, provided none
+        // can be unsound (render.go:147-150 drops such a ray uncounted): else they are generated and looked at like any other
+        if (pass.cull_pixels && found == 0 && bt.safe_camera) {
             n_total += (uint32_t)pass.sample_count;
             n_left += (uint32_t)pass.sample_count;
             n_culled += (uint32_t)pass.sample_count;
@@ -1213,7 +1215,12 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
                 fx = (float)(o.x + shift.x); fy = (float)(o.y + shift.y); fz = (float)(o.z + shift.z);
             }
             bool sound = traced && d_sound;
-            if (!bt.safe_camera) sound = sound && !(PYR ? bad3(d) : bad3(o));  // render.go:147-150
+            if (!bt.safe_camera) {  // render.go:147-150
+                // (a branch, made so by the empty statement: as a select the three classifications run in every round of every
+                // pixel although the host has nearly always ruled the case out -- 4 % of the 4K scan frame)
+                asm volatile("");
+                sound = sound && !(PYR ? bad3(d) : bad3(o));
+            }
             BeamHit bh{false, __builtin_inff(), 0, kMaxFloat, 0, 0};
             bool walking = beam_long;  // wave-uniform
             if (walking && p == pb) beam_restart<PYR>(px_state);  // this round's walk starts over

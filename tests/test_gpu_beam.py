@@ -122,6 +122,27 @@ def test_pixels_with_long_lists_change_hands(monkeypatch):
         assert np.array_equal(films["queue"][0], films[name][0]), name
 
 
+def test_camera_whose_rays_can_be_unsound(ob, monkeypatch):
+    """An orthographic camera with a field of view near the end of the float64 range: the host cannot rule out origins that are
+    not finite, so the kernel looks at every ray (render.go:147-150) -- here a share of the origins overflows.  The pixel-beam
+    kernel must count and drop the same rays as the packet walk."""
+    cam = phys.OrthographicCamera(LookFrom=(1e308, 0.0, 5.0), LookAt=(1e308, 0.0, 0.0), VUp=(0.0, 1.0, 0.0), FOVHeight=2.0, FOVWidth=1.7e308)
+    sc = phys.Scene(Camera=[cam], Node=[phys.Node("sheet", phys.NewMesh(grid_mesh(n=16)), phys.DebugUV())], RenderOptions=phys.RenderOptions(5, 128, 3, 48, 32))
+    beam, packet = _both(sc, monkeypatch)
+    assert np.array_equal(beam.Image, packet.Image)
+    assert _stats(beam.Stats) == _stats(packet.Stats)
+    with ob.OracleScene(sc) as orc:
+        _, st, _, _ = orc.render(cam, sc.RenderOptions)
+    assert (beam.Stats.TotalRays, beam.Stats.RaysLeftScene) == (st.total_rays, st.rays_left_scene)
+    assert 0 < st.total_rays - st.rays_left_scene  # some rays are dropped or hit
+    # the same view with a sane width next to it: that one is ruled sound by the host and takes the branch-free path
+    cam2 = phys.OrthographicCamera(LookFrom=(0.0, 0.0, 5.0), LookAt=(0.0, 0.0, 0.0), VUp=(0.0, 1.0, 0.0), FOVHeight=2.0, FOVWidth=1e160)
+    sc2 = phys.Scene(Camera=[cam2], Node=sc.Node, RenderOptions=sc.RenderOptions)
+    beam2, packet2 = _both(sc2, monkeypatch)
+    assert np.array_equal(beam2.Image, packet2.Image)
+    assert _stats(beam2.Stats) == _stats(packet2.Stats)
+
+
 def test_tiny_and_degenerate_meshes(monkeypatch):
     # tilted: a mesh whose bounds have no thickness is never hit (AABB.hit rejects tmax <= tmin, shape.go:81-96)
     one = np.array([[[0.0, 0.0, 0.0, 0.0, 0.0], [1.0, 0.0, 0.2, 1.0, 0.0], [0.0, 1.0, 0.1, 0.0, 1.0]]])
