@@ -264,6 +264,10 @@ RT_DEV void beam_face64(const BeamTables& bt, int32_t face, V3 o, V3 d, double T
 template <bool PYR>
 RT_DEV void beam_test_compact(const BeamTables& bt, V3 o, V3 d, float fx, float fy, float fz, double T, const int32_t* compact, int n, double tmin,
                               bool sound, BeamHit& bh) {
+    // (Wave-wide "does any lane ..." questions are asked of the comparisons themselves, whose results are lane masks in scalar
+    // registers already, and answered by scalar instructions; asked of a boolean combined from several, each costs two vector
+    // instructions: 2 % of a frame with the outline culling on.)
+    const unsigned long long sound_lanes = __builtin_amdgcn_ballot_w64(sound);
     for (int i = 0; i < n; i++) {
         // the whole entry in one batch of LDS reads (every lane the same address): one round trip per entry instead of three
         // (distance, face, position), which measured 2 % on the 4K scan together with the batch of scalar loads in beam_face64
@@ -272,16 +276,32 @@ RT_DEV void beam_test_compact(const BeamTables& bt, V3 o, V3 d, float fx, float 
         const i32x4v e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3];
         const int32_t e[14] = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3], e2[0], e2[1], e2[2], e2[3], e3[0], e3[1]};
         const float tb = __int_as_float(e[12]);
-        const bool live = sound && tb <= bh.tmax32;
-        if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // the distances never decrease: nothing after this entry begins nearer
         BeamFace32 t;
         t.p0[0] = __int_as_float(e[0]); t.p0[1] = __int_as_float(e[1]); t.p0[2] = __int_as_float(e[2]);
         t.h[0] = __int_as_float(e[3]); t.h[1] = __int_as_float(e[4]); t.h[2] = __int_as_float(e[5]);
         t.g[0] = __int_as_float(e[6]); t.g[1] = __int_as_float(e[7]); t.g[2] = __int_as_float(e[8]);
         t.neg_eu = __int_as_float(e[9]); t.neg_ev = __int_as_float(e[10]); t.lim = __int_as_float(e[11]);
-        const bool maybe = live && !(PYR ? face32_rejects_dir(t, fx, fy, fz) : face32_rejects(t, fx, fy, fz));
-        RT_STAT(3, 1);
-        if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+        const bool near_enough = tb <= bh.tmax32;
+        const unsigned long long live_lanes = __builtin_amdgcn_ballot_w64(near_enough) & sound_lanes;
+        if (live_lanes == 0) break;  // the distances never decrease: nothing after this entry begins nearer
+        bool maybe;
+        if (PYR) {
+            maybe = sound && near_enough && !face32_rejects_dir(t, fx, fy, fz);
+            RT_STAT(3, 1);
+            if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+        } else {
+            float us, vs;
+            {
+#pragma clang fp contract(fast)
+                const float sx = fx - t.p0[0], sy = fy - t.p0[1], sz = fz - t.p0[2];  // face32_rejects, its three comparisons kept apart
+                us = sx * t.h[0] + sy * t.h[1] + sz * t.h[2];
+                vs = sx * t.g[0] + sy * t.g[1] + sz * t.g[2];
+            }
+            const bool in_u = !(us < t.neg_eu), in_v = !(vs < t.neg_ev), in_w = !(us + vs > t.lim);
+            RT_STAT(3, 1);
+            if ((live_lanes & __builtin_amdgcn_ballot_w64(in_u) & __builtin_amdgcn_ballot_w64(in_v) & __builtin_amdgcn_ballot_w64(in_w)) == 0) continue;
+            maybe = sound && near_enough && in_u && in_v && in_w;
+        }
         RT_STAT(4, 1);
         beam_face64<PYR>(bt, __builtin_amdgcn_readfirstlane(e[13]), o, d, T, tmin, maybe, bh);
     }
