@@ -93,7 +93,7 @@ RT_DEV bool face32_rejects_dirs(const BeamFace32& t, float cx, float cy, float c
 // position in leaf order.  A round then reads no memory until a face passes the pre-test.  A pixel with more survivors
 // keeps walking its leaf list (beam_test_prepared).
 #ifndef RT_BEAM_FACES
-#define RT_BEAM_FACES 8  // against the leaves a list holds, which share the LDS with it (launch_beam), on the 4K scan (7.8 survivors per listing pixel on average): 6 faces 67.2 ms, 8: 66.5, 10: 67.7
+#define RT_BEAM_FACES 8  // against the leaves a list holds, which share the LDS with it (launch_beam), on the 4K scan (7.8 survivors per listing pixel on average): 6 faces 67.2 ms, 8: 66.5, 10: 67.7; at a later state of the kernel 56.7 / 55.9 / 57.0
 #endif
 constexpr int kBeamFacesMax = RT_BEAM_FACES;
 constexpr int kBeamFaceDwords = 16;

@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(kTraceBlock, MODE == RT_MODE_FAST ? (MESH_ONLY
 // for the camera's direction (dev_beam.h).  The persistent single-wave workgroups and their per-XCD queues are
 // k_primary's.
 #ifndef RT_BEAM_WAVES
-#define RT_BEAM_WAVES 5  // measured on the 4K scan (items of 4 pixels, 12 compact faces): 4 waves 85.5 ms, 5 waves 78.5 ms, 6 waves (8 compact faces) 90.3 ms
+#define RT_BEAM_WAVES 5  // measured on the 4K scan (items of 4 pixels, 12 compact faces): 4 waves 85.5 ms, 5 waves 78.5 ms, 6 waves (8 compact faces) 90.3 ms; at a later state of the kernel (8 compact faces, 128 B of scratch at 5 waves) 60.3 / 55.9 / 63.1
 #endif
 
 // The tables of dev_beam.h for direction (dx, dy, dz), or (PYR) for rays from the point (dx, dy, dz): one thread per face, leaf order.
