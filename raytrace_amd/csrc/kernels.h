@@ -23,7 +23,7 @@ struct PassDesc {
     int32_t beam_cands;             // pixel beams: leaves a pixel's list holds at a time (set by launch_beam)
     uint32_t long_cap;              // pixel beams: entries of BeamTables::long_px a launch may use (set by launch_beam); a wave that finds them used up traces its long pixels itself
     uint32_t beam_serial;           // pixel beams: number of the launch (set by launch_beam): marks the entries of BeamTables::long_px that belong to it; 0: that queue is not used
-    int32_t walk_px;                // pixel beams: pixels whose trees are walked together, a lane each: block_px times a power of two, at most 16 (set by launch_beam)
+    int32_t walk_px;                // pixel beams: pixels whose trees are walked together, a lane each: block_px times a power of two, at most 32 (set by launch_beam)
     int64_t tile_begin;             // first 8x8 tile of this pass; tiles are numbered group by group
     int64_t n_pixels;               // tiles * 64 = pixels (threads) of this pass
     uint32_t seed_lo, seed_hi;
@@ -68,6 +68,7 @@ int beam_pixels_max();
 void launch_beam_prepare(const DScene& sc, int64_t n_faces, bool pyr, const double key[9], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s);  // key: the direction and the camera's two image axes, or (pyr) the point and zeros
 bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Counters* counters, const BeamTables& bt, double* film, hipStream_t s);
 int beam_walk_stride();  // dwords of a persistent wave's stretch of BeamTables::walk_scratch
+int beam_walk_waves();   // stretches a launch on the current device can need
 size_t beam_table_bytes(int64_t n_faces, size_t* off_f64, size_t* off_uv);  // one allocation: BeamFace32[n], then BeamFace64[n], then 6 doubles per face
 // tracePath for the first n.n[s] rays of every stripe s of rays[in]: closest hit, Material.Resolve, children appended to
 // rays[1 - in], lit surface points to q.surfs, emission to the film.  Scenes with a mesh: k_walk (closest hits into

@@ -975,7 +975,7 @@ __global__ void __launch_bounds__(kBlock) k_beam_prepare(DScene sc, double dx, d
 // memory: kBeamWalkPixels states, then as many lists of `cands` triples.  Dynamic LDS, all of which is free at this point: the
 // lanes' stacks (2 * cap dwords each); a walking lane's state is private to it.  `defer`: a pixel whose list goes on beyond its
 // first instalment is put into the launch's queue of such pixels (long_px, counters->long_px) instead; true: at least one was.
-constexpr int kBeamWalkPixels = 16;  // (32 measured the same as 16 on the 4K scan)
+constexpr int kBeamWalkPixels = 32;
 // What of a walk's state the item's thinning and rounds read (dev_bvh.h): T, the list's length and flags, the bundle's test
 // parameters -- kBeamKeptDwords per pixel, in this order.
 constexpr int kBeamKeptDwords = 16;
@@ -2160,6 +2160,12 @@ static unsigned persistent_grid(K kernel, size_t lds, int block = kTraceBlock) {
     return n;
 }
 
+int beam_walk_waves() {  // the most persistent waves a launch of k_beam can have on the current device: its launch bounds times the SIMDs
+    int device = 0, cus = 0;
+    (void)hipGetDevice(&device);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    return std::max(cus, 8) * RT_BEAM_WAVES * 4;
+}
 int beam_pixels_max() { return kBeamPixels; }
 
 void launch_beam_prepare(const DScene& sc, int64_t n_faces, bool pyr, const double key[9], BeamFace32* f32, BeamFace64* f64, double* uv, hipStream_t s) {
@@ -2207,14 +2213,15 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     // for a frame or a large share of one; an item's own for a small share, whose launch wants many small pieces of work.
     // Measured with 4 / 8 / 16 pixels per walk, ms per launch: the 4K scan frame 67.0 / 62.9 / 60.9, a quarter of it - / 16.2 / 15.6, an
     // eighth - / 8.40 / 8.14; the same scene at 1920x1080 20.3 / 19.1 / 18.6, a quarter of that 5.96 / 6.18 / 6.49, an eighth 4.74 / 5.05 / 5.24.
+    // Later, 16 / 32 pixels: the frame 55.9 / 55.0, a half 28.3 / 27.9, a quarter 14.4 / 14.3, an eighth 7.5 / 8.1.
     int walk_px = pass.block_px;
-    int want_walk = pass.n_pixels >= 700000 ? 16 : pass.block_px;
+    int want_walk = pass.n_pixels >= 1500000 ? 32 : (pass.n_pixels >= 700000 ? 16 : pass.block_px);
     if (const char* e = getenv("RT_BEAM_WALK_PX")) want_walk = atoi(e);  // tuning knob
     const size_t walk_lane = 2 * (size_t)sc.stack_pairs * sizeof(int32_t);  // a walking lane's stack
     while (walk_px * 2 <= want_walk && walk_px * 2 <= kBeamWalkPixels && (size_t)(walk_px * 2) * walk_lane <= lds) walk_px *= 2;
     pd.walk_px = walk_px;
     // The end of a scheduled queue in small batches: an eighth of it, at most what keeps the XCD's waves busy for a few large batches' time.
-    if (!bt.walk_scratch || bt.walk_stride < beam_walk_stride() || !bt.long_px) return false;
+    if (!bt.walk_scratch || bt.walk_stride < beam_walk_stride() || bt.walk_waves < 8 || !bt.long_px) return false;
     static std::atomic<uint32_t> serial{0};
     do pd.beam_serial = ++serial; while (pd.beam_serial == 0);
     pd.long_cap = kBeamLongCap;
@@ -2223,7 +2230,7 @@ bool launch_beam(const DScene& sc, const DCamera* cam, const PassDesc& pass, Cou
     const unsigned tiles = trace_blocks((uint64_t)pass.n_pixels);
     auto go = [&](auto kernel) {
         const unsigned resident = persistent_grid(kernel, lds);
-        const unsigned waves = std::min(std::min(resident, (tiles + 7u) & ~7u), (unsigned)kBeamWalkWaves);  // (a stretch of walk_scratch each)
+        const unsigned waves = std::min(std::min(resident, (tiles + 7u) & ~7u), (unsigned)bt.walk_waves & ~7u);  // (a stretch of walk_scratch each)
         hipLaunchKernelGGL(kernel, dim3(waves), dim3(kTraceBlock), lds, s, sc, cam, pd, counters, bt, film);
     };
     if (bt.pyramid) { if (bt.image) go(k_beam<true, true, RT_BEAM_WAVES>); else go(k_beam<false, true, RT_BEAM_WAVES>); }

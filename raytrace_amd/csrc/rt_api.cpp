@@ -651,9 +651,10 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             rep->beam.image = d->materials[nodes[0].material].kind == RT_MAT_EMITTER &&
                               d->textures[d->materials[nodes[0].material].texture].kind == RT_TEX_IMAGE;
             rep->beam_faces = n;
-            // a stretch per persistent wave for the walks of 16 pixels: their states and lists of up to kBeamCandsMax leaves (159 MB)
+            // a stretch per persistent wave for the walks of 32 pixels: their states and lists of up to kBeamCandsMax leaves (199 MB on 256 CUs)
             rep->beam.walk_stride = beam_walk_stride();
-            HIP_TRY(rep->mem.alloc((size_t)kBeamWalkWaves * (size_t)rep->beam.walk_stride, &rep->beam.walk_scratch));
+            rep->beam.walk_waves = beam_walk_waves();
+            HIP_TRY(rep->mem.alloc((size_t)rep->beam.walk_waves * (size_t)rep->beam.walk_stride, &rep->beam.walk_scratch));
             HIP_TRY(rep->mem.alloc((size_t)kBeamLongCap, &rep->beam.long_px));
             HIP_TRY(hipMemset(rep->beam.long_px, 0, (size_t)kBeamLongCap * sizeof(unsigned long long)));  // (no launch has the number 0)
         }

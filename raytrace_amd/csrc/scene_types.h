@@ -163,10 +163,10 @@ struct BeamTables {
     int32_t image;        // 1: the material is an Emitter whose texture is a TextureImage (the kernel samples it in line)
     int32_t pyramid;      // 0: the tables are for a direction (orthographic camera); 1: for a point every ray starts from (pinhole camera, focusable camera without aperture)
     int32_t walk_stride;     // dwords of a wave's stretch of walk_scratch
-    int32_t* walk_scratch;   // kBeamWalkWaves stretches, one per persistent wave of k_beam: the states and lists of the pixels whose trees it has just walked (kernels.hip, beam_walk_batch)
+    int32_t walk_waves;      // stretches in walk_scratch
+    int32_t* walk_scratch;   // one stretch per persistent wave of k_beam: the states and lists of the pixels whose trees it has just walked (kernels.hip, beam_walk_batch)
     unsigned long long* long_px;  // kBeamLongCap entries: the pixels of a launch whose rounds walk the tree again (milliseconds each), handed from the wave that met them to whichever wave draws next (kernels.hip, k_beam)
 };
-constexpr int kBeamWalkWaves = 8192;
 constexpr uint32_t kBeamLongCap = 1u << 20;  // (a wave that finds the queue full traces the pixel itself)
 
 struct DCamera {

@@ -97,7 +97,7 @@ def test_long_lists_and_odd_views(ob, monkeypatch, view):
 def test_pixels_with_long_lists_change_hands(monkeypatch):
     """A sheet seen along its plane at 512 x 512 x 512 samples: many pixels list more leaves than a list holds.  The wave that
     meets such a pixel in a batch of walks hands it on through the launch's queue of long pixels, and whichever wave draws next
-    traces it as an item of its own.  Frames rendered that way (batches of the default size and of 16 pixels), with a queue of
+    traces it as an item of its own.  Frames rendered that way (batches of the default size, of 16 and of 32 pixels), with a queue of
     five entries (when it is full a wave keeps what it meets), with every wave keeping what it meets (RT_NO_LONG_QUEUE=1) and by
     the packet walk must be the same film, number for number: a pixel's sum
     is one wave's, added in one order, whoever traces it."""
@@ -108,7 +108,7 @@ def test_pixels_with_long_lists_change_hands(monkeypatch):
     sc = phys.Scene(Camera=[cam], Node=[phys.Node("sheet", phys.NewMesh(grid_mesh()), phys.Emitter(tex))],
                     RenderOptions=phys.RenderOptions(3, 512, 4, 512, 512))
     films = {}
-    for name, env in (("queue", {}), ("queue16", {"RT_BEAM_WALK_PX": "16"}), ("full", {"RT_BEAM_WALK_PX": "16", "RT_BEAM_LONG_CAP": "5"}),
+    for name, env in (("queue", {}), ("queue16", {"RT_BEAM_WALK_PX": "16"}), ("queue32", {"RT_BEAM_WALK_PX": "32"}), ("full", {"RT_BEAM_WALK_PX": "16", "RT_BEAM_LONG_CAP": "5"}),
                       ("kept", {"RT_NO_LONG_QUEUE": "1"}), ("packet", {"RT_NO_BEAM": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -116,9 +116,9 @@ def test_pixels_with_long_lists_change_hands(monkeypatch):
             films[name] = _film(dev, lib, sc, frames=2)  # pilot + 510 samples from the plain order; 512 samples from the schedule
         for k in env:
             monkeypatch.delenv(k)
-    assert films["queue"][1] == films["queue16"][1] == films["full"][1] == films["kept"][1] == films["packet"][1]
+    assert films["queue"][1] == films["queue16"][1] == films["queue32"][1] == films["full"][1] == films["kept"][1] == films["packet"][1]
     assert films["queue"][1][1] < films["queue"][1][0]  # something is hit
-    for name in ("queue16", "full", "kept", "packet"):
+    for name in ("queue16", "queue32", "full", "kept", "packet"):
         assert np.array_equal(films["queue"][0], films[name][0]), name
 
 
