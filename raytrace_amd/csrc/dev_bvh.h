@@ -21,7 +21,7 @@ struct VisitCounts {
 
 // Diagnostics (builds with -DRT_VISIT_STATS only): events per wave, summed over the launch.
 #ifdef RT_WAVE_TIMES  // diagnostics build: when the persistent waves of k_beam begin and end
-__device__ unsigned long long g_wave_times[4 * 8192];  // per wave: start, end (constant-rate clock), items traced
+__device__ unsigned long long g_wave_times[4 * 8192];  // per wave: start, end of its last item (constant-rate clock), items traced and the last two in detail (k_beam)
 #endif
 #ifdef RT_VISIT_STATS
 __device__ unsigned long long g_packet_stats[16];  // packet walk: walks, inner nodes, leaves, float32 face tests, float64 face tests, pops, pushes, -, cycles in walks, cycles in rounds, rounds, cycles in leaves

@@ -1455,8 +1455,8 @@ __global__ void __launch_bounds__(kTraceBlock, WAVES) k_beam(DScene sc, const DC
     if (p == 0 && blockIdx.x < 8192) {
         g_wave_times[4 * blockIdx.x] = wave_t0;
         g_wave_times[4 * blockIdx.x + 1] = wave_last_end;   // (the end of its last item: some waves stay on to look for long pixels)
-        g_wave_times[4 * blockIdx.x + 2] = wave_items | (wave_last << 16);
-        g_wave_times[4 * blockIdx.x + 3] = (wave_prev & 0xffffffull) | ((unsigned long long)wave_last_tile << 24);  // items; from bit 16: the last item's duration (32 bits), then 1 if it was a long pixel
+        g_wave_times[4 * blockIdx.x + 2] = wave_items | (wave_last << 16);  // items; from bit 16: the last item's duration (32 bits), then 1 if it was a long pixel
+        g_wave_times[4 * blockIdx.x + 3] = (wave_prev & 0xffffffull) | ((unsigned long long)wave_last_tile << 24);  // the duration of the item before it; from bit 24: the last item's first pixel (tile * 64 + pixel)
     }
 #endif
     if (p == 0) {  // the tallies are per wave already
