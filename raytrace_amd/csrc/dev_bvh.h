@@ -1173,9 +1173,8 @@ RT_DEV int beam_compact_prefix(const int32_t* cand, int n, int capacity, int& n_
 
 // A sample's search state over the instalments of its pixel's list.
 struct BeamHit {
-    bool hit;
     float tmax32;  // the search limit (t) in the bundle's frame, rounded up
-    int prim;      // leaf-order position of the face hit
+    int prim;      // leaf-order position of the face hit; -1: none yet
     double t;      // the closest hit so far; before the first one, the search limit
     double u, v;
 };

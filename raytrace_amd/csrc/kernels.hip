@@ -1221,7 +1221,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
                 asm volatile("");
                 sound = sound && !(PYR ? bad3(d) : bad3(o));
             }
-            BeamHit bh{false, __builtin_inff(), 0, kMaxFloat, 0, 0};
+            BeamHit bh{__builtin_inff(), -1, kMaxFloat, 0, 0};
             bool walking = beam_long;  // wave-uniform
             if (walking && p == pb) beam_restart<PYR>(px_state);  // this round's walk starts over
 #ifdef RT_VISIT_STATS
@@ -1255,8 +1255,8 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
             RT_STAT(12, clock64() - faces_t0);
             RT_STAT(10, 1);
 #endif
-            n_left += (uint32_t)__popcll(__ballot(sound && !bh.hit));  // render.go:170-173
-            if (sound && bh.hit) {
+            n_left += (uint32_t)__popcll(__ballot(sound && bh.prim < 0));  // render.go:170-173
+            if (sound && bh.prim >= 0) {
                 if (IMG) {  // Face.Collide's texture coordinates (shape_mesh.go:131-140), Emitter.Resolve (material_emitter.go:22-25) with radiance (1, 1, 1)
                     const double* uv6 = bt.uv + (size_t)bh.prim * 6;
                     const double wgt = 1 - bh.u - bh.v;
