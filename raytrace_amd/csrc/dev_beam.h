@@ -260,14 +260,14 @@ RT_DEV void beam_face64(const BeamTables& bt, int32_t face, V3 o, V3 d, double T
 }
 
 // The n compact entries of a pixel against this lane's ray.  Must be entered by the lanes of a wave together.
+// sound_lanes: the lanes whose `sound` is set, as the caller has them.
 // (fx, fy, fz): the ray's origin in the bundle's float32 frame, or (PYR) its direction.
 template <bool PYR>
 RT_DEV void beam_test_compact(const BeamTables& bt, V3 o, V3 d, float fx, float fy, float fz, double T, const int32_t* compact, int n, double tmin,
-                              bool sound, BeamHit& bh) {
+                              bool sound, unsigned long long sound_lanes, BeamHit& bh) {
     // (Wave-wide "does any lane ..." questions are asked of the comparisons themselves, whose results are lane masks in scalar
     // registers already, and answered by scalar instructions; asked of a boolean combined from several, each costs two vector
     // instructions: 2 % of a frame with the outline culling on.)
-    const unsigned long long sound_lanes = __builtin_amdgcn_ballot_w64(sound);
     for (int i = 0; i < n; i++) {
         // the whole entry in one batch of LDS reads (every lane the same address): one round trip per entry instead of three
         // (distance, face, position), which measured 2 % on the 4K scan together with the batch of scalar loads in beam_face64

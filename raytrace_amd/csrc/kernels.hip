@@ -1215,11 +1215,13 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
                 fx = (float)(o.x + shift.x); fy = (float)(o.y + shift.y); fz = (float)(o.z + shift.z);
             }
             bool sound = traced && d_sound;
+            unsigned long long sound_lanes = d_sound ? __ballot(traced) : 0ull;  // (of the comparison itself: a scalar register pair; see beam_test_compact)
             if (!bt.safe_camera) {  // render.go:147-150
                 // (a branch, made so by the empty statement: as a select the three classifications run in every round of every
                 // pixel although the host has nearly always ruled the case out -- 4 % of the 4K scan frame)
                 asm volatile("");
                 sound = sound && !(PYR ? bad3(d) : bad3(o));
+                sound_lanes = __ballot(sound);
             }
             BeamHit bh{__builtin_inff(), -1, kMaxFloat, 0, 0};
             bool walking = beam_long;  // wave-uniform
@@ -1228,7 +1230,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
             const long long faces_t0 = clock64();
 #endif
             if (use_compact) {
-                beam_test_compact<PYR>(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, bh);
+                beam_test_compact<PYR>(bt, o, d, fx, fy, fz, beam_T, px_compact, n_compact, kEps, sound, sound_lanes, bh);
                 if (beam_resume < beam_first)
                     beam_test_prepared<PYR>(bt, o, d, fx, fy, fz, beam_T, px_cand + 3 * beam_resume, beam_first - beam_resume, true, kEps, sound, bh);
             } else do {
@@ -1255,7 +1257,7 @@ RT_DEV void beam_item(const DScene& sc, const DCamera& cam, const PassDesc& pass
             RT_STAT(12, clock64() - faces_t0);
             RT_STAT(10, 1);
 #endif
-            n_left += (uint32_t)__popcll(__ballot(sound && bh.prim < 0));  // render.go:170-173
+            n_left += (uint32_t)__popcll(sound_lanes & __ballot(bh.prim < 0));  // render.go:170-173
             if (sound && bh.prim >= 0) {
                 if (IMG) {  // Face.Collide's texture coordinates (shape_mesh.go:131-140), Emitter.Resolve (material_emitter.go:22-25) with radiance (1, 1, 1)
                     const double* uv6 = bt.uv + (size_t)bh.prim * 6;
