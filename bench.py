@@ -46,11 +46,13 @@ VALU_PEAK_GINST = SIMDS * PEAK_CLOCK_HZ / 4.0 / 1e9  # wave instructions per sec
 # pixel whose bundle lists at least one face (the others end after the camera ray).
 VALU_FLOOR = [
     # stage, who pays, wave instructions, what they are
-    ("philox", "every ray", 60, "Philox4x32-10, one block for the two jitter draws: 10 rounds x (2 mul_hi + 2 mul_lo + 2 three-input xor), keys bumped by the scalar unit"),
+    ("philox", "every ray", 58, "Philox4x32-10, one block for the two jitter draws: 10 rounds x (2 multiplies 32 x 32 -> 64 + 4 two-input xors; gfx950 has no "
+                                "three-input xor), less the first round's two products of wave-uniform counter words; keys bumped by the scalar unit"),
     ("draws", "every ray", 8, "two float64 in [0, 1) from four 32-bit words: 2 x (2 conversions, 1 multiply-add pair)"),
     ("jitter", "every ray", 8, "render.go:202-210: 2 x (add, exactly rounded division by Dx / Dy in 3)"),
     ("camera", "every ray", 16, "camera_orthographic.go:24-46: 2 x (subtract, multiply) + 3 x (2 multiplies, 2 adds)"),
-    ("guard", "every ray", 3, "render.go:147-150: one class test per origin component (the direction is wave-uniform)"),
+    ("guard", "every ray", 0, "render.go:147-150: nothing per ray for a camera whose constants the host has found finite and far from the float64 range "
+                              "(this frame's; otherwise one class test per origin component)"),
     ("frame", "listed", 12, "origin in the bundle's float32 frame: 3 x (multiply, add, subtract, conversion)"),
     ("pretest", "listed", 15, "one float32 face pre-test: s = o - p0 (3), two dot products (6), margins and compares (6)"),
     ("face", "hit", 36, "shape_mesh.go:95-124 for ONE face, with what does not depend on the ray (edges, d x e2, 1/a) taken as given: "
@@ -60,7 +62,7 @@ VALU_FLOOR = [
     ("texture", "hit", 96, "texture_image.go:87-188 bilinear, repeat: wrap and scale (12), floor / fraction (6), 4 texel addresses (8), "
                            "16 channel unpack + premultiply (32), 9 lerps x 3 (27), truncations to 16 bits (3), / 65535 exactly (9) minus alpha never read"),
     ("emit", "hit", 6, "material_emitter.go:22-25 and the pixel's running sum: 3 multiplies, 3 adds"),
-    ("loop", "every ray", 4, "round counter, sample index, live mask"),
+    ("loop", "every ray", 2, "sample index, live mask (the round counter is scalar)"),
 ]
 
 
