@@ -51,8 +51,8 @@ VALU_FLOOR = [
     ("draws", "every ray", 8, "two float64 in [0, 1) from four 32-bit words: 2 x (2 conversions, 1 multiply-add pair)"),
     ("jitter", "every ray", 8, "render.go:202-210: 2 x (add, exactly rounded division by Dx / Dy in 3)"),
     ("camera", "every ray", 16, "camera_orthographic.go:24-46: 2 x (subtract, multiply) + 3 x (2 multiplies, 2 adds)"),
-    ("guard", "every ray", 0, "render.go:147-150: nothing per ray for a camera whose constants the host has found finite and far from the float64 range "
-                              "(this frame's; otherwise one class test per origin component)"),
+    # (render.go:147-150, the NaN / Inf guard: nothing per ray for a camera whose constants the host has found finite and far from the end
+    # of the float64 range, as this frame's are; otherwise one class test per origin component)
     ("frame", "listed", 12, "origin in the bundle's float32 frame: 3 x (multiply, add, subtract, conversion)"),
     ("pretest", "listed", 15, "one float32 face pre-test: s = o - p0 (3), two dot products (6), margins and compares (6)"),
     ("face", "hit", 36, "shape_mesh.go:95-124 for ONE face, with what does not depend on the ray (edges, d x e2, 1/a) taken as given: "
